@@ -1,0 +1,180 @@
+/* wire_hip.h -- C ABI of libwire_hip.so: the MI355X (gfx950) WIRE INR hot path.
+ *
+ * The reference (Annatk26/wire @ 2024_08_07) has no native layer and no FFI:
+ * its hot path is eager PyTorch.  Each entry point
+ * below names the reference code whose arithmetic it replaces; the binding a
+ * maintainer adds on the reference side is a ctypes stub.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *    the name ends in _host; `stream` is a hipStream_t passed as void*.
+ *  - every function returns 0 on success or a negative wire_status; it never
+ *    throws and never synchronises the device.  wire_last_error() returns the
+ *    message of the calling thread's most recent failure.
+ *  - the library owns no device memory: parameters, packed weights,
+ *    activations and scratch live in caller buffers sized by the *_floats /
+ *    *_bytes queries.  Re-entrant; callable from any host thread (autograd
+ *    runs backward on its own thread).
+ *  - "params" / "grads" are arrays (in HOST memory) of device pointers, one
+ *    per trainable tensor in the reference's state_dict order and native
+ *    layout (complex64 = interleaved re,im floats):
+ *       wire   : W0[K][D] f32, b0[K] f32, {W_l[K][K] c64, b_l[K] c64} l=1..L,
+ *                W_f[O][K] c64, b_f[O] c64        (modules/wire.py:127-157)
+ *       wire2d : per layer l=0..L: W, b, V(scale_orth), c; then W_f, b_f
+ *                                                  (modules/wire2d.py:98-123)
+ *       siren/gauss/relu : {W_l, b_l} l=0..L, W_f, b_f, all f32
+ *                (modules/siren.py:64-88, gauss.py:44-67, relu.py:99-120)
+ *  - internal activation layout ("blocked planar"): a
+ *    complex row of K features is stored as P = roundup(2K,64) floats; group
+ *    g of 32 features occupies columns [64g,64g+32) = real parts and
+ *    [64g+32,64g+64) = imaginary parts.  Pad features read as 0.
+ */
+#ifndef WIRE_HIP_H
+#define WIRE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WIRE_ABI_VERSION 1
+
+typedef enum wire_status {
+  WIRE_OK = 0,
+  WIRE_ERR_ARG = -1,     /* bad argument / unsupported shape            */
+  WIRE_ERR_HIP = -2,     /* a HIP runtime call or launch failed          */
+  WIRE_ERR_SIZE = -3     /* caller buffer too small                      */
+} wire_status;
+
+/* model_dict keys of modules/models.py:15-21 that are in scope */
+typedef enum wire_kind {
+  WIRE_KIND_WIRE = 0,    /* modules/wire.py   ComplexGaborLayer          */
+  WIRE_KIND_WIRE2D = 1,  /* modules/wire2d.py ComplexGaborLayer2D        */
+  WIRE_KIND_SIREN = 2,   /* modules/siren.py  SineLayer                  */
+  WIRE_KIND_GAUSS = 3,   /* modules/gauss.py  GaussLayer                 */
+  WIRE_KIND_RELU = 4     /* modules/relu.py   ReLULayer (+PosEncoding)   */
+} wire_kind;
+
+/* Architecture + hyper-parameters of one INR (modules/wire.py:96-159). */
+typedef struct wire_net_desc {
+  int32_t kind;            /* wire_kind                                           */
+  int32_t in_features;     /* D: coordinate dims (2 or 3)                         */
+  int32_t width;           /* K: features per hidden layer AFTER the reference's
+                              own rescale (int(h/sqrt2) wire, int(h/2) wire2d)   */
+  int32_t hidden_layers;   /* L                                                   */
+  int32_t out_features;    /* O (<= 8)                                            */
+  int32_t posenc_freqs;    /* relu only: PosEncoding.num_frequencies, 0 = off     */
+  float first_omega0;      /* omega of net[0]                                     */
+  float hidden_omega0;     /* omega of net[1..L]                                  */
+  float scale0;            /* Gaussian scale s0                                   */
+} wire_net_desc;
+
+int wire_abi_version(void);
+const char* wire_last_error(void);
+
+/* ---- sizes ------------------------------------------------------------ */
+/* number of trainable tensors (length of the params / grads arrays)       */
+int wire_num_param_tensors(const wire_net_desc* d);
+/* floats in tensor t in its native layout (complex counts 2 per element)  */
+int64_t wire_param_tensor_floats(const wire_net_desc* d, int t);
+/* floats of the packed (padded, real-expanded) weight image               */
+int64_t wire_packed_floats(const wire_net_desc* d);
+/* bytes of activation storage mlp_fwd writes for `n` rows (save_for_bwd=1
+ * keeps what mlp_bwd needs; 0 = inference ping-pong only)                  */
+int64_t wire_act_bytes(const wire_net_desc* d, int64_t n, int save_for_bwd);
+/* bytes of scratch mlp_bwd needs for `n` rows                              */
+int64_t wire_bwd_scratch_bytes(const wire_net_desc* d, int64_t n);
+
+/* ---- whole-network path ------------------------------------------------ */
+/* Refresh the packed weight image from the native parameters.  Call after
+ * every optimizer step (replaces nothing in the reference: ATen reads the
+ * nn.Parameter storage directly, modules/wire.py:89).                      */
+int wire_pack_params(void* stream, const wire_net_desc* d,
+                     const void* const* params_host, float* packed);
+
+/* INR.forward (modules/wire.py:161-167; wire2d.py:122-127; siren.py:90-96;
+ * gauss.py:71-74; relu.py:124-130): coords[n][D] f32 -> y[n][O] f32.
+ * `act` receives the per-layer activations (wire_act_bytes).               */
+int wire_mlp_fwd(void* stream, const wire_net_desc* d, const float* packed,
+                 const float* coords, int64_t n, float* y,
+                 void* act, int64_t act_bytes, int save_for_bwd);
+
+/* Backward of the above (autograd graph of modules/wire.py:89-93,156-165):
+ * g_y[n][O] = dL/dy.  Writes every parameter gradient in native layout
+ * (PyTorch complex convention dL/dRe + j dL/dIm) through `grads_host`;
+ * grads are OVERWRITTEN (= zero_grad + backward).                          */
+int wire_mlp_bwd(void* stream, const wire_net_desc* d, const float* packed,
+                 const float* coords, int64_t n, const float* g_y,
+                 const void* act, int64_t act_bytes,
+                 void* scratch, int64_t scratch_bytes,
+                 void* const* grads_host);
+
+/* ---- per-layer path (ComplexGaborLayer.forward, modules/wire.py:88-93) -- */
+/* x: [n][in] f32 when is_first else [n][in] c64; W: [out][in] f32/c64;
+ * act_out [n][out] c64 (interleaved); lin_out (optional, may be NULL) has the
+ * dtype of W's product: f32 [n][out] if is_first else c64.
+ * ws: scratch of wire_layer_ws_bytes(n, in, out).                          */
+int64_t wire_layer_ws_bytes(int64_t n, int in_features, int out_features);
+int wire_gabor_fwd(void* stream, const void* x, const void* W, const void* b,
+                   float omega0, float scale0, int64_t n, int in_features,
+                   int out_features, int is_first, void* lin_out,
+                   void* act_out, void* ws, int64_t ws_bytes);
+/* backward: g_act [n][out] c64 -> g_x (NULL when is_first), g_W, g_b.      */
+int wire_gabor_bwd(void* stream, const void* g_act, const void* x,
+                   const void* W, const void* b, float omega0, float scale0,
+                   int64_t n, int in_features, int out_features, int is_first,
+                   void* g_x, void* g_W, void* g_b, void* ws, int64_t ws_bytes);
+/* final nn.Linear(K,O,cfloat) + .real (modules/wire.py:156-157,164-165)    */
+int wire_final_fwd(void* stream, const void* z, const void* Wf, const void* bf,
+                   int64_t n, int in_features, int out_features, float* y,
+                   void* ws, int64_t ws_bytes);
+int wire_final_bwd(void* stream, const float* g_y, const void* z,
+                   const void* Wf, int64_t n, int in_features,
+                   int out_features, void* g_z, void* g_Wf, void* g_bf,
+                   void* ws, int64_t ws_bytes);
+
+/* ---- training-step glue (wire_image_denoise.py:142-157,
+ *      wire_occupancy.py:137-158) ---------------------------------------- */
+/* coords[r] = grid point of flat index idx[r] (idx NULL -> first + r).
+ * 2-D (tz NULL): idx = i*W + j -> (tx[j], ty[i])   (wire_image_denoise.py:63-66)
+ * 3-D: idx = (i*W + j)*T + k -> (tx[j], ty[i], tz[k]) (modules/utils.py:171-176)
+ * tx/ty/tz are the caller's linspace tables (device).                      */
+int wire_coords_from_index(void* stream, const int64_t* idx, int64_t first,
+                           int64_t n, const float* tx, int W, const float* ty,
+                           int H, const float* tz, int T, float* coords);
+/* loss = mean((y - target[idx])^2) over n*O elements scaled by `weight`
+ * (= n/B for a shard of a global batch B; 1 for a whole batch);
+ * g_y = weight * 2/(n*O) * (y - t).  loss_out[0] += is NOT used: it is
+ * overwritten.  rec (optional): rec[idx[r]][:] = y[r][:]
+ * (wire_image_denoise.py:150-153).  partial: scratch of >= 4096 floats.    */
+int wire_mse_grad(void* stream, const float* y, const float* target,
+                  const int64_t* idx, int64_t first, int64_t n, int O,
+                  float weight, float* g_y, float* loss_out, float* rec,
+                  float* partial);
+/* torch.optim.Adam single step over a flat fp32 buffer (complex tensors as
+ * real pairs; wire_image_denoise.py:123-125).  step is 1-based.            */
+int wire_adam_step_flat(void* stream, float* param, const float* grad,
+                        float* exp_avg, float* exp_avg_sq, int64_t count,
+                        float lr, float beta1, float beta2, float eps,
+                        int64_t step);
+
+/* ---- layout helpers ---------------------------------------------------- */
+int wire_blocked_width(int K);   /* P = roundup(2K, 64) */
+int wire_c64_to_blocked(void* stream, const void* src, int64_t n, int K, float* dst);
+int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* dst);
+
+/* ---- profiling hooks (bench.py roofline) -------------------------------
+ * When enabled, every launch of the hot kernels is bracketed by hipEvents on
+ * the launch stream; wire_prof_read synchronises those events and returns
+ * per-class totals.  Classes: 0 fwd GEMM, 1 dgrad GEMM, 2 wgrad GEMM,
+ * 3 everything else.                                                       */
+#define WIRE_PROF_CLASSES 4
+int wire_prof_enable(int on);
+int wire_prof_read(double* ms_total, int64_t* launches, double* flops_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WIRE_HIP_H */

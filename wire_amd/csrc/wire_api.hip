@@ -1,0 +1,491 @@
+// wire_api.hip -- the C ABI of libwire_hip.so (include/wire_hip.h): argument
+// checking, buffer carving and the launch sequences of the WIRE hot path.
+// No device memory is allocated here; every launch goes on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/wire_hip.h"
+#include "wire_gemm.h"
+#include "wire_point.h"
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return fail(WIRE_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                 \
+  } while (0)
+
+int wire_fail_(int code, const char* msg) { return fail(code, "%s", msg); }   // wire_layer_api.hip
+
+extern "C" int wire_abi_version(void) { return WIRE_ABI_VERSION; }
+extern "C" const char* wire_last_error(void) { return g_err.c_str(); }
+
+// ---------------------------------------------------------------------------
+// profiling hooks
+// ---------------------------------------------------------------------------
+namespace {
+struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+
+struct ProfScope {
+  hipStream_t s; int cls; double flops; bool on; hipEvent_t a{}, b{};
+  ProfScope(hipStream_t s_, int cls_, double flops_) : s(s_), cls(cls_), flops(flops_), on(false) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_on) return;
+    on = true;
+    if (!g_prof_pool.empty()) {
+      a = g_prof_pool.back().first; b = g_prof_pool.back().second; g_prof_pool.pop_back();
+    } else {
+      hipEventCreate(&a); hipEventCreate(&b);
+    }
+    hipEventRecord(a, s);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    hipEventRecord(b, s);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_recs.push_back({a, b, cls, flops});
+  }
+};
+}  // namespace
+
+extern "C" int wire_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+  return WIRE_OK;
+}
+extern "C" int wire_prof_read(double* ms_total, int64_t* launches, double* flops_total) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (int i = 0; i < WIRE_PROF_CLASSES; ++i) { ms_total[i] = 0; launches[i] = 0; flops_total[i] = 0; }
+  for (auto& r : g_prof_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      ms_total[r.cls] += ms; launches[r.cls] += 1; flops_total[r.cls] += r.flops;
+    }
+    g_prof_pool.emplace_back(r.a, r.b);
+  }
+  g_prof_recs.clear();
+  return WIRE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// network plan
+// ---------------------------------------------------------------------------
+namespace {
+inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+struct Plan {
+  int kind, D, K, L, O, F;
+  float w1, w, s;
+  bool cplx, first_gemm;
+  int P, Pl, Din, Pin0, ldu, ntens, per_layer;
+  // packed image offsets (floats); index l = 0..L (l = 0 only when first_gemm)
+  std::vector<int64_t> off_fwd, off_dg, off_bias;
+  int64_t off_wf, off_bf, off_first, total_packed;
+  std::vector<int64_t> tfloats;
+};
+
+int make_plan(const wire_net_desc* d, Plan& p) {
+  if (!d) return fail(WIRE_ERR_ARG, "null descriptor");
+  p.kind = d->kind; p.D = d->in_features; p.K = d->width; p.L = d->hidden_layers;
+  p.O = d->out_features; p.F = d->posenc_freqs;
+  p.w1 = d->first_omega0; p.w = d->hidden_omega0; p.s = d->scale0;
+  if (p.kind < WIRE_KIND_WIRE || p.kind > WIRE_KIND_RELU) return fail(WIRE_ERR_ARG, "unknown kind %d", p.kind);
+  if (p.D < 1 || p.D > 4) return fail(WIRE_ERR_ARG, "in_features %d outside 1..4", p.D);
+  if (p.K < 1 || p.K > 4096) return fail(WIRE_ERR_ARG, "width %d outside 1..4096", p.K);
+  if (p.L < 0 || p.L > 64) return fail(WIRE_ERR_ARG, "hidden_layers %d outside 0..64", p.L);
+  if (p.O < 1 || p.O > 8) return fail(WIRE_ERR_ARG, "out_features %d outside 1..8", p.O);
+  if (p.F < 0 || (p.F > 0 && p.kind != WIRE_KIND_RELU)) return fail(WIRE_ERR_ARG, "posenc only with relu");
+  p.cplx = (p.kind == WIRE_KIND_WIRE || p.kind == WIRE_KIND_WIRE2D);
+  p.P = p.cplx ? rup(2 * p.K, 64) : rup(p.K, 64);
+  p.Pl = (p.kind == WIRE_KIND_WIRE2D) ? 2 * p.P : p.P;
+  p.ldu = p.P / 2;
+  p.first_gemm = p.F > 0;
+  p.Din = p.first_gemm ? p.D + 2 * p.D * p.F : p.D;
+  p.Pin0 = p.first_gemm ? rup(p.Din, 64) : 0;
+  p.per_layer = (p.kind == WIRE_KIND_WIRE2D) ? 4 : 2;
+  p.ntens = p.per_layer * (p.L + 1) + 2;
+  p.tfloats.assign(p.ntens, 0);
+  const int64_t K = p.K, cm = p.cplx ? 2 : 1;
+  for (int l = 0; l <= p.L; ++l) {
+    const int64_t in = (l == 0) ? p.Din : K;
+    const int64_t m = (l == 0) ? 1 : cm;   // first layer is real-valued
+    for (int q = 0; q < p.per_layer; q += 2) {
+      p.tfloats[p.per_layer * l + q] = m * K * in;
+      p.tfloats[p.per_layer * l + q + 1] = m * K;
+    }
+  }
+  p.tfloats[p.ntens - 2] = cm * p.O * K;
+  p.tfloats[p.ntens - 1] = cm * p.O;
+  // packed image
+  int64_t off = 0;
+  p.off_fwd.assign(p.L + 1, -1); p.off_dg.assign(p.L + 1, -1); p.off_bias.assign(p.L + 1, -1);
+  for (int l = p.first_gemm ? 0 : 1; l <= p.L; ++l) {
+    const int64_t pin = (l == 0) ? p.Pin0 : p.P;
+    p.off_fwd[l] = off; off += (int64_t)p.Pl * pin;
+    p.off_dg[l] = off; off += (int64_t)p.Pl * pin;
+    p.off_bias[l] = off; off += p.Pl;
+  }
+  p.off_wf = off; off += (int64_t)p.O * p.P;
+  p.off_bf = off; off += 64;
+  p.off_first = off;   // native copies of the first layer's tensors (W0,b0[,V0,c0])
+  if (!p.first_gemm) for (int q = 0; q < p.per_layer; ++q) off += rup((int)p.tfloats[q], 4);
+  p.total_packed = off;
+  return WIRE_OK;
+}
+
+inline int64_t first_native_off(const Plan& p, int q) {
+  int64_t off = p.off_first;
+  for (int i = 0; i < q; ++i) off += rup((int)p.tfloats[i], 4);
+  return off;
+}
+
+// activation carve (floats)
+struct ActLayout {
+  int64_t pe, out0, lin0, lin1, total;   // out_l = out0 + l*n*P ; lin_l = lin1 + (l-1)*n*Pl
+  int64_t ping, pong;                    // inference
+};
+ActLayout act_layout(const Plan& p, int64_t n, int save) {
+  ActLayout a{};
+  int64_t off = 0;
+  a.pe = off; if (p.first_gemm) off += n * p.Pin0;
+  if (save) {
+    a.out0 = off; off += n * p.P * (p.L + 1);
+    a.lin0 = off; if (!p.cplx) off += n * p.P;
+    a.lin1 = off; off += n * p.Pl * p.L;
+  } else {
+    a.ping = off; off += n * p.P;
+    a.pong = off; off += n * p.P;
+  }
+  a.total = off;
+  return a;
+}
+
+struct ScratchLayout { int64_t ga, gb, gu, slab, bslab, fpw, fpb, crp, total; int S; };
+ScratchLayout scratch_layout(const Plan& p, int64_t n) {
+  ScratchLayout s{};
+  int64_t off = 0;
+  s.ga = off; off += n * p.Pl;
+  s.gb = off; off += n * p.Pl;
+  s.gu = off; if (p.cplx) off += n * p.ldu * (p.kind == WIRE_KIND_WIRE2D ? 2 : 1);
+  s.S = gemm_tn_splits(n, p.Pl, p.first_gemm && p.Pin0 > p.P ? p.Pin0 : p.P, 64);
+  const int64_t pn = p.first_gemm && p.Pin0 > p.P ? p.Pin0 : p.P;
+  s.slab = off; off += (int64_t)s.S * p.Pl * pn;
+  s.bslab = off; off += (int64_t)s.S * p.Pl;
+  const int nbf = final_bwd_blocks(n);
+  s.fpw = off; off += (int64_t)nbf * p.O * p.P;
+  s.fpb = off; off += (int64_t)nbf * p.O + 64;
+  s.crp = off; off += (int64_t)colreduce_blocks(n) * (p.cplx ? p.ldu : p.P) * 5;
+  s.total = off;
+  return s;
+}
+
+int epi_fwd(int kind) {
+  switch (kind) {
+    case WIRE_KIND_WIRE: return EPI_GABOR_FWD;
+    case WIRE_KIND_WIRE2D: return EPI_GABOR2D_FWD;
+    case WIRE_KIND_SIREN: return EPI_SIREN_FWD;
+    case WIRE_KIND_GAUSS: return EPI_GAUSS_FWD;
+    default: return EPI_RELU_FWD;
+  }
+}
+int epi_bwd(int kind) {
+  switch (kind) {
+    case WIRE_KIND_WIRE: return EPI_GABOR_BWD;
+    case WIRE_KIND_WIRE2D: return EPI_GABOR2D_BWD;
+    case WIRE_KIND_SIREN: return EPI_SIREN_BWD;
+    case WIRE_KIND_GAUSS: return EPI_GAUSS_BWD;
+    default: return EPI_RELU_BWD;
+  }
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// size queries
+// ---------------------------------------------------------------------------
+extern "C" int wire_num_param_tensors(const wire_net_desc* d) {
+  Plan p; if (make_plan(d, p)) return WIRE_ERR_ARG;
+  return p.ntens;
+}
+extern "C" int64_t wire_param_tensor_floats(const wire_net_desc* d, int t) {
+  Plan p; if (make_plan(d, p)) return WIRE_ERR_ARG;
+  if (t < 0 || t >= p.ntens) return fail(WIRE_ERR_ARG, "tensor index %d out of range", t);
+  return p.tfloats[t];
+}
+extern "C" int64_t wire_packed_floats(const wire_net_desc* d) {
+  Plan p; if (make_plan(d, p)) return WIRE_ERR_ARG;
+  return p.total_packed;
+}
+extern "C" int64_t wire_act_bytes(const wire_net_desc* d, int64_t n, int save_for_bwd) {
+  Plan p; if (make_plan(d, p)) return WIRE_ERR_ARG;
+  if (n < 0) return fail(WIRE_ERR_ARG, "negative n");
+  return act_layout(p, n, save_for_bwd).total * 4 + 256;
+}
+extern "C" int64_t wire_bwd_scratch_bytes(const wire_net_desc* d, int64_t n) {
+  Plan p; if (make_plan(d, p)) return WIRE_ERR_ARG;
+  if (n < 0) return fail(WIRE_ERR_ARG, "negative n");
+  return scratch_layout(p, n).total * 4 + 256;
+}
+extern "C" int wire_blocked_width(int K) { return rup(2 * K, 64); }
+
+// ---------------------------------------------------------------------------
+// pack
+// ---------------------------------------------------------------------------
+extern "C" int wire_pack_params(void* stream, const wire_net_desc* d, const void* const* params,
+                                float* packed) {
+  Plan p; if (int rc = make_plan(d, p)) return rc;
+  if (!params || !packed) return fail(WIRE_ERR_ARG, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(s, 3, 0);
+  for (int i = 0; i < p.ntens; ++i)
+    if (!params[i]) return fail(WIRE_ERR_ARG, "params[%d] is null", i);
+  for (int l = p.first_gemm ? 0 : 1; l <= p.L; ++l) {
+    const float* W = (const float*)params[p.per_layer * l];
+    const float* b = (const float*)params[p.per_layer * l + 1];
+    const float* V = p.per_layer == 4 ? (const float*)params[p.per_layer * l + 2] : nullptr;
+    const float* c = p.per_layer == 4 ? (const float*)params[p.per_layer * l + 3] : nullptr;
+    const int kin = (l == 0) ? p.Din : p.K;
+    const int pin = (l == 0) ? p.Pin0 : p.P;
+    HIPCHK(launch_pack_hidden(s, p.kind, W, b, V, c, p.K, kin, p.P, pin, packed + p.off_fwd[l],
+                              packed + p.off_dg[l], packed + p.off_bias[l]));
+  }
+  HIPCHK(launch_pack_final(s, p.kind, (const float*)params[p.ntens - 2],
+                           (const float*)params[p.ntens - 1], p.K, p.P, p.O, packed + p.off_wf,
+                           packed + p.off_bf));
+  if (!p.first_gemm)
+    for (int q = 0; q < p.per_layer; ++q)
+      HIPCHK(hipMemcpyAsync(packed + first_native_off(p, q), params[q], p.tfloats[q] * 4,
+                            hipMemcpyDeviceToDevice, s));
+  return WIRE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// whole-network forward
+// ---------------------------------------------------------------------------
+extern "C" int wire_mlp_fwd(void* stream, const wire_net_desc* d, const float* packed,
+                            const float* coords, int64_t n, float* y, void* act, int64_t act_bytes,
+                            int save_for_bwd) {
+  Plan p; if (int rc = make_plan(d, p)) return rc;
+  if (n < 0) return fail(WIRE_ERR_ARG, "negative n");
+  if (n == 0) return WIRE_OK;
+  if (!packed || !coords || !y || !act) return fail(WIRE_ERR_ARG, "null pointer");
+  const ActLayout a = act_layout(p, n, save_for_bwd);
+  if (act_bytes < a.total * 4) return fail(WIRE_ERR_SIZE, "act buffer %lld < %lld bytes",
+                                           (long long)act_bytes, (long long)a.total * 4);
+  hipStream_t s = (hipStream_t)stream;
+  float* A = (float*)act;
+  auto out_l = [&](int l) { return save_for_bwd ? A + a.out0 + (int64_t)l * n * p.P
+                                                : A + ((l & 1) ? a.pong : a.ping); };
+  auto lin_l = [&](int l) -> float* {
+    if (!save_for_bwd) return nullptr;
+    return l == 0 ? A + a.lin0 : A + a.lin1 + (int64_t)(l - 1) * n * p.Pl;
+  };
+  // ---- layer 0
+  if (p.first_gemm) {
+    { ProfScope ps(s, 3, 0);
+      HIPCHK(launch_posenc(s, coords, n, p.D, p.F, p.Pin0, A + a.pe)); }
+    GemmEpiParams ep; ep.bias = packed + p.off_bias[0]; ep.o0 = lin_l(0); ep.o1 = out_l(0);
+    ep.ld0 = p.Pl; ep.ld1 = p.P; ep.omega = p.w1; ep.scale = p.s; ep.kvalid = p.K;
+    ProfScope ps(s, 0, 2.0 * n * p.Pl * p.Pin0);
+    HIPCHK(launch_gemm_nt(s, epi_fwd(p.kind), A + a.pe, p.Pin0, packed + p.off_fwd[0], p.Pin0, n,
+                          p.Pl, p.Pin0, ep));
+  } else {
+    const float* W0 = packed + first_native_off(p, 0);
+    const float* b0 = packed + first_native_off(p, 1);
+    const float* V0 = p.per_layer == 4 ? packed + first_native_off(p, 2) : nullptr;
+    const float* c0 = p.per_layer == 4 ? packed + first_native_off(p, 3) : nullptr;
+    ProfScope ps(s, 3, 0);
+    HIPCHK(launch_first_fwd(s, p.kind, coords, n, p.D, W0, b0, V0, c0, p.K, p.P, p.w1, p.s,
+                            p.cplx ? nullptr : lin_l(0), out_l(0)));
+  }
+  // ---- hidden layers
+  for (int l = 1; l <= p.L; ++l) {
+    GemmEpiParams ep; ep.bias = packed + p.off_bias[l]; ep.o0 = lin_l(l); ep.o1 = out_l(l);
+    ep.ld0 = p.Pl; ep.ld1 = p.P; ep.omega = p.w; ep.scale = p.s; ep.kvalid = p.K;
+    ProfScope ps(s, 0, 2.0 * n * p.Pl * p.P);
+    HIPCHK(launch_gemm_nt(s, epi_fwd(p.kind), out_l(l - 1), p.P, packed + p.off_fwd[l], p.P, n,
+                          p.Pl, p.P, ep));
+  }
+  { ProfScope ps(s, 3, 0);
+    HIPCHK(launch_final_fwd(s, out_l(p.L), n, p.P, p.O, packed + p.off_wf, packed + p.off_bf, y)); }
+  return WIRE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// whole-network backward
+// ---------------------------------------------------------------------------
+extern "C" int wire_mlp_bwd(void* stream, const wire_net_desc* d, const float* packed,
+                            const float* coords, int64_t n, const float* g_y, const void* act,
+                            int64_t act_bytes, void* scratch, int64_t scratch_bytes,
+                            void* const* grads) {
+  Plan p; if (int rc = make_plan(d, p)) return rc;
+  if (n <= 0) return fail(WIRE_ERR_ARG, "backward needs n > 0");
+  if (!packed || !coords || !g_y || !act || !scratch || !grads) return fail(WIRE_ERR_ARG, "null pointer");
+  for (int i = 0; i < p.ntens; ++i) if (!grads[i]) return fail(WIRE_ERR_ARG, "grads[%d] is null", i);
+  const ActLayout a = act_layout(p, n, 1);
+  const ScratchLayout sc = scratch_layout(p, n);
+  if (act_bytes < a.total * 4) return fail(WIRE_ERR_SIZE, "act buffer too small");
+  if (scratch_bytes < sc.total * 4) return fail(WIRE_ERR_SIZE, "scratch %lld < %lld bytes",
+                                                (long long)scratch_bytes, (long long)sc.total * 4);
+  hipStream_t s = (hipStream_t)stream;
+  const float* A = (const float*)act;
+  float* Sx = (float*)scratch;
+  auto out_l = [&](int l) { return A + a.out0 + (int64_t)l * n * p.P; };
+  auto lin_l = [&](int l) { return l == 0 ? A + a.lin0 : A + a.lin1 + (int64_t)(l - 1) * n * p.Pl; };
+  float* gcur = Sx + sc.ga;
+  float* gnext = Sx + sc.gb;
+
+  // ---- final linear + activation gradient of layer L
+  const int nbf = final_bwd_blocks(n);
+  {
+    ProfScope ps(s, 3, 0);
+    const float wL = (p.L == 0) ? p.w1 : p.w;
+    if (p.L == 0 && p.cplx) {
+      // no hidden layer: g_out0 is needed raw; handled below through the raw path
+      HIPCHK(launch_final_bwd(s, p.kind, 1, g_y, n, p.O, packed + p.off_wf, nullptr, out_l(0), p.K,
+                              p.P, wL, p.s, gcur, Sx + sc.fpw, Sx + sc.fpb));
+    } else {
+      HIPCHK(launch_final_bwd(s, p.kind, 0, g_y, n, p.O, packed + p.off_wf, lin_l(p.L), out_l(p.L),
+                              p.K, p.P, wL, p.s, gcur, Sx + sc.fpw, Sx + sc.fpb));
+    }
+    HIPCHK(launch_final_reduce(s, p.kind, Sx + sc.fpw, Sx + sc.fpb, nbf, p.O, p.K, p.P,
+                               (float*)grads[p.ntens - 2], (float*)grads[p.ntens - 1]));
+  }
+  if (p.L == 0 && p.cplx) return fail(WIRE_ERR_ARG, "hidden_layers = 0 is not supported for complex nets");
+
+  // ---- hidden layers L..1
+  for (int l = p.L; l >= 1; --l) {
+    float* gW = (float*)grads[p.per_layer * l];
+    float* gb = (float*)grads[p.per_layer * l + 1];
+    float* gV = p.per_layer == 4 ? (float*)grads[p.per_layer * l + 2] : nullptr;
+    float* gc = p.per_layer == 4 ? (float*)grads[p.per_layer * l + 3] : nullptr;
+    {
+      const int S = gemm_tn_splits(n, p.Pl, p.P, sc.S);
+      { ProfScope ps(s, 2, 2.0 * n * p.Pl * p.P);
+        HIPCHK(launch_gemm_tn(s, gcur, p.Pl, out_l(l - 1), p.P, n, p.Pl, p.P, S, Sx + sc.slab,
+                              Sx + sc.bslab)); }
+      ProfScope ps(s, 3, 0);
+      HIPCHK(launch_wgrad_reduce(s, p.kind, Sx + sc.slab, Sx + sc.bslab, S, p.K, p.K, p.Pl, p.P, gW,
+                                 gb, gV, gc));
+    }
+    GemmEpiParams ep;
+    ep.scale = p.s; ep.kvalid = p.K; ep.ld1 = p.P; ep.i1 = out_l(l - 1);
+    int epi;
+    if (l > 1 || !p.cplx) {
+      epi = epi_bwd(p.kind);
+      ep.omega = (l - 1 == 0) ? p.w1 : p.w;
+      ep.i0 = lin_l(l - 1); ep.o0 = gnext; ep.ld0 = p.Pl;
+    } else {
+      epi = (p.kind == WIRE_KIND_WIRE) ? EPI_GABOR_BWD_FIRST : EPI_GABOR2D_BWD_FIRST;
+      ep.omega = p.w1;
+      ep.coords = coords; ep.D = p.D; ep.ldu = p.ldu; ep.o0 = Sx + sc.gu;
+      ep.W0 = packed + first_native_off(p, 0); ep.b0 = packed + first_native_off(p, 1);
+      if (p.per_layer == 4) { ep.W0b = packed + first_native_off(p, 2); ep.b0b = packed + first_native_off(p, 3); }
+    }
+    if (!p.cplx && l == 1) ep.ld0 = p.P;
+    { ProfScope ps(s, 1, 2.0 * n * p.Pl * p.P);
+      HIPCHK(launch_gemm_nt(s, epi, gcur, p.Pl, packed + p.off_dg[l], p.Pl, n, p.P, p.Pl, ep)); }
+    float* t = gcur; gcur = gnext; gnext = t;
+  }
+
+  // ---- first layer parameter gradients
+  ProfScope ps(s, 3, 0);
+  if (p.cplx) {
+    const float* gu = Sx + sc.gu;
+    if (p.kind == WIRE_KIND_WIRE) {
+      HIPCHK(launch_colreduce(s, gu, p.ldu, p.K, coords, p.D, n, Sx + sc.crp, (float*)grads[0],
+                              (float*)grads[1]));
+    } else {
+      HIPCHK(launch_colreduce(s, gu, 2 * p.ldu, p.K, coords, p.D, n, Sx + sc.crp, (float*)grads[0],
+                              (float*)grads[1]));
+      HIPCHK(launch_colreduce(s, gu + p.ldu, 2 * p.ldu, p.K, coords, p.D, n, Sx + sc.crp,
+                              (float*)grads[2], (float*)grads[3]));
+    }
+  } else if (!p.first_gemm) {
+    // gcur holds g_lin_0 [n][P]
+    const float* g0 = (p.L == 0) ? Sx + sc.ga : gcur;
+    HIPCHK(launch_colreduce(s, g0, p.P, p.K, coords, p.D, n, Sx + sc.crp, (float*)grads[0],
+                            (float*)grads[1]));
+  } else {
+    const float* g0 = (p.L == 0) ? Sx + sc.ga : gcur;
+    const int S = gemm_tn_splits(n, p.P, p.Pin0, sc.S);
+    HIPCHK(launch_gemm_tn(s, g0, p.P, A + a.pe, p.Pin0, n, p.P, p.Pin0, S, Sx + sc.slab,
+                          Sx + sc.bslab));
+    HIPCHK(launch_wgrad_reduce(s, p.kind, Sx + sc.slab, Sx + sc.bslab, S, p.K, p.Din, p.P, p.Pin0,
+                               (float*)grads[0], (float*)grads[1], nullptr, nullptr));
+  }
+  return WIRE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// training glue
+// ---------------------------------------------------------------------------
+extern "C" int wire_coords_from_index(void* stream, const int64_t* idx, int64_t first, int64_t n,
+                                      const float* tx, int W, const float* ty, int H,
+                                      const float* tz, int T, float* coords) {
+  if (n < 0 || !tx || !ty || !coords || W < 1 || H < 1 || (tz && T < 1))
+    return fail(WIRE_ERR_ARG, "bad argument to wire_coords_from_index");
+  ProfScope ps((hipStream_t)stream, 3, 0);
+  HIPCHK(launch_coords((hipStream_t)stream, idx, first, n, tx, W, ty, H, tz, T, coords));
+  return WIRE_OK;
+}
+extern "C" int wire_mse_grad(void* stream, const float* y, const float* target, const int64_t* idx,
+                             int64_t first, int64_t n, int O, float weight, float* g_y,
+                             float* loss_out, float* rec, float* partial) {
+  if (n < 0 || O < 1 || !y || !target || !g_y || !loss_out || !partial)
+    return fail(WIRE_ERR_ARG, "bad argument to wire_mse_grad");
+  ProfScope ps((hipStream_t)stream, 3, 0);
+  HIPCHK(launch_mse_grad((hipStream_t)stream, y, target, idx, first, n, O, weight, g_y, loss_out,
+                         rec, partial));
+  return WIRE_OK;
+}
+extern "C" int wire_adam_step_flat(void* stream, float* param, const float* grad, float* exp_avg,
+                                   float* exp_avg_sq, int64_t count, float lr, float beta1,
+                                   float beta2, float eps, int64_t step) {
+  if (count < 0 || step < 1 || !param || !grad || !exp_avg || !exp_avg_sq)
+    return fail(WIRE_ERR_ARG, "bad argument to wire_adam_step_flat");
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  ProfScope ps((hipStream_t)stream, 3, 0);
+  HIPCHK(launch_adam((hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, count,
+                     (float)((double)lr / bc1), beta1, beta2, eps, (float)(1.0 / std::sqrt(bc2))));
+  return WIRE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// layout helpers
+// ---------------------------------------------------------------------------
+extern "C" int wire_c64_to_blocked(void* stream, const void* src, int64_t n, int K, float* dst) {
+  if (n < 0 || K < 1 || !src || !dst) return fail(WIRE_ERR_ARG, "bad argument");
+  HIPCHK(launch_c64_to_blocked((hipStream_t)stream, (const float*)src, n, K, rup(2 * K, 64), dst));
+  return WIRE_OK;
+}
+extern "C" int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* dst) {
+  if (n < 0 || K < 1 || !src || !dst) return fail(WIRE_ERR_ARG, "bad argument");
+  HIPCHK(launch_blocked_to_c64((hipStream_t)stream, src, n, K, rup(2 * K, 64), (float*)dst));
+  return WIRE_OK;
+}

@@ -1,0 +1,140 @@
+// wire_dev.h -- device-side helpers shared by the gfx950 kernels.
+//
+// Everything here is wave64 / CDNA4 code; there is no other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define WIRE_DEVINL __device__ __forceinline__
+
+// ---- blocked-planar complex layout --------------------------------------
+// feature o, part c (0 = re, 1 = im) -> column in a row of P floats.
+WIRE_DEVINL int blk_col(int o, int part) { return ((o >> 5) << 6) + (part << 5) + (o & 31); }
+// inverse: column -> (feature, part)
+WIRE_DEVINL void blk_decode(int col, int& o, int& part) {
+  o = ((col >> 6) << 5) + (col & 31);
+  part = (col >> 5) & 1;
+}
+
+// ---- transcendental kernels ---------------------------------------------
+// exp(a) as exp2 on the hardware unit (v_exp_f32) with the rounding error of
+// a*log2(e) folded back in: ~1-2 ulp for every a the Gabor envelope produces.
+WIRE_DEVINL float wire_exp(float a) {
+  const float L2E_HI = 1.44269502e+00f;   // float(log2 e)
+  const float L2E_LO = 1.92596299e-08f;   // log2 e - L2E_HI
+  const float LN2 = 6.93147182e-01f;
+  float t = a * L2E_HI;
+  float tl = __builtin_fmaf(a, L2E_HI, -t) + a * L2E_LO;
+  float e = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(e, tl * LN2, e);
+}
+
+// sin and cos of x with a 3-constant Cody-Waite reduction by pi/2 (fma keeps
+// every partial product unrounded) and cephes-grade minimax polynomials on
+// [-pi/4, pi/4].  Arguments here are omega0*u with |x| well below 1e5, where
+// the reduction error stays under 1 ulp of the reduced argument.
+WIRE_DEVINL void wire_sincos(float x, float& sn, float& cs) {
+  const float TWO_OVER_PI = 6.36619747e-01f;
+  const float C1 = 1.57079637e+00f;    // float(pi/2)
+  const float C2 = -4.37113883e-08f;   // float(pi/2 - C1)
+  const float C3 = -1.71512451e-15f;   // pi/2 - C1 - C2
+  float n = __builtin_rintf(x * TWO_OVER_PI);
+  float r = __builtin_fmaf(-n, C1, x);
+  r = __builtin_fmaf(-n, C2, r);
+  r = __builtin_fmaf(-n, C3, r);
+  int q = (int)n;
+  float z = r * r;
+  float sp = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+  sp = __builtin_fmaf(sp, z, -1.6666654611e-1f);
+  float s = __builtin_fmaf(sp * z, r, r);
+  float cp = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+  cp = __builtin_fmaf(cp, z, 4.166664568298827e-2f);
+  float c = __builtin_fmaf(cp * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+  float a = (q & 1) ? c : s;
+  float b = (q & 1) ? s : c;
+  sn = (q & 2) ? -a : a;
+  cs = ((q + 1) & 2) ? -b : b;
+}
+
+// ---- activation math (shared by the GEMM epilogues and the point kernels) --
+// Complex Gabor, modules/wire.py:90-93:  out = exp(j w0 lin - |s0 lin|^2)
+WIRE_DEVINL void gabor_fwd(float u, float v, float w0, float s0, float& o_re, float& o_im) {
+  float su = s0 * u, sv = s0 * v;
+  float ar = -(w0 * v) - __builtin_fmaf(su, su, sv * sv);
+  float e = wire_exp(ar);
+  float sn, cs;
+  wire_sincos(w0 * u, sn, cs);
+  o_re = e * cs;
+  o_im = e * sn;
+}
+// first layer: lin is real (v = 0)
+WIRE_DEVINL void gabor_fwd_real(float u, float w0, float s0, float& o_re, float& o_im) {
+  float su = s0 * u;
+  float e = wire_exp(-(su * su));
+  float sn, cs;
+  wire_sincos(w0 * u, sn, cs);
+  o_re = e * cs;
+  o_im = e * sn;
+}
+// backward, SURVEY 8(a) row a4: c = conj(out) g, P = Re c,
+//   g_lin = -2 s0^2 P lin - j w0 c
+WIRE_DEVINL void gabor_bwd(float gr, float gi, float u, float v, float o_re, float o_im,
+                           float w0, float m2s2, float& gl_re, float& gl_im) {
+  float c_re = __builtin_fmaf(o_re, gr, o_im * gi);
+  float c_im = __builtin_fmaf(o_re, gi, -(o_im * gr));
+  float t = m2s2 * c_re;
+  gl_re = __builtin_fmaf(t, u, w0 * c_im);
+  gl_im = __builtin_fmaf(t, v, -(w0 * c_re));
+}
+// first layer: g_u = -2 s0^2 u P + w0 Im c
+WIRE_DEVINL float gabor_bwd_real(float gr, float gi, float u, float o_re, float o_im,
+                                 float w0, float m2s2) {
+  float c_re = __builtin_fmaf(o_re, gr, o_im * gi);
+  float c_im = __builtin_fmaf(o_re, gi, -(o_im * gr));
+  return __builtin_fmaf(m2s2 * c_re, u, w0 * c_im);
+}
+
+// 2-D Gabor, modules/wire2d.py:56-67:
+//   out = exp(j w0 lin) exp(-s0^2 (|lin|^2 + |sy|^2))
+WIRE_DEVINL void gabor2d_fwd(float u, float v, float p, float q, float w0, float s0,
+                             float& o_re, float& o_im) {
+  // exp(j w0 (u + j v)) = exp(-w0 v) (cos w0 u + j sin w0 u)
+  float arg = __builtin_fmaf(u, u, v * v) + __builtin_fmaf(p, p, q * q);
+  float e = wire_exp(-(w0 * v) - (s0 * s0) * arg);
+  float sn, cs;
+  wire_sincos(w0 * u, sn, cs);
+  o_re = e * cs;
+  o_im = e * sn;
+}
+
+// real sweep activations (config 5)
+enum { ACT_SIREN = 0, ACT_GAUSS = 1, ACT_RELU = 2 };
+template <int ACT>
+WIRE_DEVINL float real_act_fwd(float lin, float w0, float s0) {
+  if (ACT == ACT_SIREN) {            // modules/siren.py:48-49
+    float sn, cs;
+    wire_sincos(w0 * lin, sn, cs);
+    return sn;
+  } else if (ACT == ACT_GAUSS) {     // modules/gauss.py:27-28
+    float t = s0 * lin;
+    return wire_exp(-(t * t));
+  } else {                           // modules/relu.py:28-29
+    return lin > 0.f ? lin : 0.f;
+  }
+}
+template <int ACT>
+WIRE_DEVINL float real_act_bwd(float g, float lin, float out, float w0, float s0) {
+  if (ACT == ACT_SIREN) {
+    float sn, cs;
+    wire_sincos(w0 * lin, sn, cs);
+    return g * w0 * cs;
+  } else if (ACT == ACT_GAUSS) {
+    return g * out * (-2.f * s0 * s0) * lin;
+  } else {
+    return lin > 0.f ? g : 0.f;
+  }
+}

@@ -1,0 +1,49 @@
+// wire_gemm.h -- host-visible declarations of the fp32-MFMA GEMM launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// Epilogue selector of the NT GEMM  C[M][Nc] = A[M][Kd] * Bt[Nc][Kd]^T.
+enum WireEpi {
+  EPI_STORE = 0,            // o0 = C
+  EPI_GABOR_FWD = 1,        // C = lin(re|im): o0 = lin (optional), o1 = gabor(lin + bias)
+  EPI_GABOR_BWD = 2,        // C = g_out: i0 = lin, i1 = out -> o0 = g_lin
+  EPI_GABOR_BWD_FIRST = 3,  // C = g_out0: i1 = out0, coords/W0/b0 -> u; o0 = g_u [M][ldu]
+  EPI_SIREN_FWD = 4, EPI_GAUSS_FWD = 5, EPI_RELU_FWD = 6,   // o0 = lin, o1 = act
+  EPI_SIREN_BWD = 7, EPI_GAUSS_BWD = 8, EPI_RELU_BWD = 9,   // i0 = lin, i1 = out -> o0 = g_lin
+  EPI_GABOR2D_FWD = 10,     // C = (lin|sy)(re|im) 128-col groups: o0 = linsy [M][2P], o1 = out [M][P]
+  EPI_GABOR2D_BWD = 11,     // C = g_out: i0 = linsy, i1 = out -> o0 = g_linsy [M][2P]
+  EPI_GABOR2D_BWD_FIRST = 12  // real first layer of wire2d: o0 = g_(u|p) [M][2*ldu]
+};
+
+struct GemmEpiParams {
+  const float* bias = nullptr;   // [Nc], GEMM column order
+  float* o0 = nullptr;
+  float* o1 = nullptr;
+  const float* i0 = nullptr;
+  const float* i1 = nullptr;
+  int ld0 = 0;                   // leading dim (floats) of o0 / i0
+  int ld1 = 0;                   // leading dim of o1 / i1
+  float omega = 0.f, scale = 0.f;
+  int kvalid = 0;                // valid features (complex count for Gabor, real count otherwise)
+  // first-layer backward extras
+  const float* coords = nullptr; // [M][D]
+  const float* W0 = nullptr;     // [K][D] (wire2d: followed by V0 via W0b)
+  const float* b0 = nullptr;     // [K]
+  const float* W0b = nullptr;    // wire2d scale_orth weight [K][D]
+  const float* b0b = nullptr;
+  int D = 0;
+  int ldu = 0;
+};
+
+// C = A * Bt^T with fused epilogue.  A [M][lda], Bt [Nc][ldb]; Nc % 64 == 0,
+// Kd % 32 == 0, lda/ldb % 4 == 0.
+hipError_t launch_gemm_nt(hipStream_t s, int epi, const float* A, int lda, const float* Bt,
+                          int ldb, int64_t M, int Nc, int Kd, const GemmEpiParams& ep);
+
+// Split-over-rows TN GEMM  slab[s][Pm][Pn] = G[rows_s][Pm]^T * Z[rows_s][Pn]
+// (+ optional column sums of G into bslab[s][Pm]).  Returns the number of
+// row splits used through *splits (<= max_splits).
+int gemm_tn_splits(int64_t n, int Pm, int Pn, int max_splits);
+hipError_t launch_gemm_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz,
+                          int64_t n, int Pm, int Pn, int splits, float* slab, float* bslab);

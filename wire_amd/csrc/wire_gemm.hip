@@ -1,0 +1,571 @@
+// wire_gemm.hip -- fp32-MFMA GEMM kernels for gfx950 with fused WIRE epilogues.
+//
+// Two kernels carry >99 % of the flops of the WIRE hot path:
+//
+//  gemm_nt_kernel : C[M][Nc] = A[M][Kd] * Bt[Nc][Kd]^T   (both operands
+//      K-contiguous).  Used for the layer forward (A = activations, Bt = real-
+//      expanded weights) and for the data gradient (A = g_lin, Bt = the
+//      transposed image).  The epilogue applies bias + the Gabor / SIREN /
+//      Gauss / ReLU nonlinearity (forward) or the closed-form activation
+//      gradient (backward) on the accumulators, so lin/out/g_lin are each
+//      written exactly once and never re-read by an elementwise kernel.
+//      Replaces ATen addmm + ~8 elementwise ops per layer
+//      (reference modules/wire.py:88-93).
+//
+//  gemm_tn_kernel : slab[s] = G[rows_s]^T * Z[rows_s]    (weight gradient,
+//      reduction over the sample axis split across workgroups; partial slabs
+//      are summed deterministically by reduce kernels in wire_point.hip).
+//
+// Tiling (both): 128x128 output tile per 256-thread workgroup, 4 waves, each
+// wave a 64x64 (or 32x128) block of v_mfma_f32_32x32x2_f32 tiles, BK = 32,
+// double-buffered LDS, two workgroups per CU so one workgroup's epilogue
+// (VALU transcendental work) overlaps the other's MFMA stream.
+#include "wire_dev.h"
+#include "wire_gemm.h"
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define LDS_STRIDE 36   // floats per LDS row: 32 + 4 pad -> conflict-free ds_read_b128
+
+// ---------------------------------------------------------------------------
+// epilogue bodies: one complex feature (re, im accumulators of the same lane)
+// ---------------------------------------------------------------------------
+template <int EPI>
+struct EpiTraits {
+  static constexpr bool complex_pair = (EPI == EPI_GABOR_FWD || EPI == EPI_GABOR_BWD ||
+                                        EPI == EPI_GABOR_BWD_FIRST);
+  static constexpr bool quad = (EPI == EPI_GABOR2D_FWD);
+};
+
+template <int EPI, int MT, int WN>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ Bt, int ldb, int M, int Nc,
+    int Kd, int tiles_m, int tiles_n, GemmEpiParams ep) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * LDS_STRIDE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  constexpr int WAVES_N = BN / (WN * 32);
+  const int wave_m = wave / WAVES_N;
+  const int wave_n = wave % WAVES_N;
+  const int l31 = lane & 31;
+  const int h = lane >> 5;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch),
+  // so the tiles_n column tiles of one row tile run back-to-back on one L2.
+  const int b = blockIdx.x;
+  const int xcd = b & 7;
+  const int idx = b >> 3;
+  const int ct = idx % tiles_n;
+  const int rt = (idx / tiles_n) * 8 + xcd;
+  if (rt >= tiles_m) return;
+  const int m_base = rt * BM;
+  const int n_base = ct * BN;
+
+  // ---- global -> register staging map: 8 threads x float4 per 32-float row
+  const int lrow = tid >> 3;
+  const int lc4 = (tid & 7) * 4;
+  const float* a_src[4];
+  const float* b_src[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    int ra = m_base + lrow + 32 * p;
+    ra = ra < M ? ra : M - 1;
+    int rb = n_base + lrow + 32 * p;
+    rb = rb < Nc ? rb : Nc - 1;
+    a_src[p] = A + (size_t)ra * lda + lc4;
+    b_src[p] = Bt + (size_t)rb * ldb + lc4;
+  }
+  const int st_off = lrow * LDS_STRIDE + lc4;
+
+  f32x16 acc[MT][WN];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const bool wave_live = (n_base + wave_n * (WN * 32)) < Nc;
+  const int nk = Kd / BK;
+
+  f32x4 ra4[4], rb4[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    ra4[p] = *reinterpret_cast<const f32x4*>(a_src[p]);
+    rb4[p] = *reinterpret_cast<const f32x4*>(b_src[p]);
+  }
+  {
+    float* As = smem;
+    float* Bs = smem + BM * LDS_STRIDE;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *reinterpret_cast<f32x4*>(&As[st_off + 32 * p * LDS_STRIDE]) = ra4[p];
+      *reinterpret_cast<f32x4*>(&Bs[st_off + 32 * p * LDS_STRIDE]) = rb4[p];
+    }
+  }
+  __syncthreads();
+
+  const int a_rd = (wave_m * (MT * 32) + l31) * LDS_STRIDE + 4 * h;
+  const int b_rd = (wave_n * (WN * 32) + l31) * LDS_STRIDE + 4 * h;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const bool more = (kt + 1) < nk;
+    if (more) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        ra4[p] = *reinterpret_cast<const f32x4*>(a_src[p] + (kt + 1) * BK);
+        rb4[p] = *reinterpret_cast<const f32x4*>(b_src[p] + (kt + 1) * BK);
+      }
+    }
+    const float* As = smem + buf * (2 * BM * LDS_STRIDE);
+    const float* Bs = As + BM * LDS_STRIDE;
+    if (wave_live) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 af[MT], bf[WN];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          af[i] = *reinterpret_cast<const f32x4*>(&As[a_rd + i * 32 * LDS_STRIDE + 8 * q]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          bf[j] = *reinterpret_cast<const f32x4*>(&Bs[b_rd + j * 32 * LDS_STRIDE + 8 * q]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (more) {
+      float* Aw = smem + (buf ^ 1) * (2 * BM * LDS_STRIDE);
+      float* Bw = Aw + BM * LDS_STRIDE;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        *reinterpret_cast<f32x4*>(&Aw[st_off + 32 * p * LDS_STRIDE]) = ra4[p];
+        *reinterpret_cast<f32x4*>(&Bw[st_off + 32 * p * LDS_STRIDE]) = rb4[p];
+      }
+    }
+    __syncthreads();
+  }
+  if (!wave_live) return;
+
+  // ------------------------------------------------------------------ epilogue
+  // accumulator element r of tile (i, j): row = m_w + 32 i + (r&3) + 8 (r>>2) + 4 h,
+  // column = n_w + 32 j + (lane & 31).
+  const int m_w = m_base + wave_m * (MT * 32);
+  const int n_w = n_base + wave_n * (WN * 32);
+
+  if constexpr (EPI == EPI_STORE) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int col = n_w + 32 * j + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m_w + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < M) ep.o0[(size_t)row * ep.ld0 + col] = acc[i][j][r];
+        }
+      }
+  } else if constexpr (EPI == EPI_GABOR_FWD) {
+    // tile pair (j, j+1) = (re, im) of 32 complex features
+#pragma unroll
+    for (int jp = 0; jp < WN; jp += 2) {
+      const int c_re = n_w + 32 * jp + l31;
+      const int c_im = c_re + 32;
+      const int feat = ((c_re >> 6) << 5) + l31;
+      const float b_re = ep.bias[c_re];
+      const float b_im = ep.bias[c_im];
+      const bool valid = feat < ep.kvalid;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m_w + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float u = acc[i][jp][r] + b_re;
+          const float v = acc[i][jp + 1][r] + b_im;
+          float o_re, o_im;
+          gabor_fwd(u, v, ep.omega, ep.scale, o_re, o_im);
+          if (!valid) { o_re = 0.f; o_im = 0.f; }
+          if (row < M) {
+            if (ep.o0) {
+              ep.o0[(size_t)row * ep.ld0 + c_re] = u;
+              ep.o0[(size_t)row * ep.ld0 + c_im] = v;
+            }
+            ep.o1[(size_t)row * ep.ld1 + c_re] = o_re;
+            ep.o1[(size_t)row * ep.ld1 + c_im] = o_im;
+          }
+        }
+    }
+  } else if constexpr (EPI == EPI_GABOR_BWD) {
+    const float m2s2 = -2.f * ep.scale * ep.scale;
+#pragma unroll
+    for (int jp = 0; jp < WN; jp += 2) {
+      const int c_re = n_w + 32 * jp + l31;
+      const int c_im = c_re + 32;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m_w + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < M) {
+            const size_t o0 = (size_t)row * ep.ld0;
+            const size_t o1 = (size_t)row * ep.ld1;
+            const float u = ep.i0[o0 + c_re], v = ep.i0[o0 + c_im];
+            const float pr = ep.i1[o1 + c_re], pi = ep.i1[o1 + c_im];
+            float gl_re, gl_im;
+            gabor_bwd(acc[i][jp][r], acc[i][jp + 1][r], u, v, pr, pi, ep.omega, m2s2, gl_re, gl_im);
+            ep.o0[o0 + c_re] = gl_re;
+            ep.o0[o0 + c_im] = gl_im;
+          }
+        }
+    }
+  } else if constexpr (EPI == EPI_GABOR_BWD_FIRST) {
+    const float m2s2 = -2.f * ep.scale * ep.scale;
+#pragma unroll
+    for (int jp = 0; jp < WN; jp += 2) {
+      const int c_re = n_w + 32 * jp + l31;
+      const int c_im = c_re + 32;
+      const int feat = ((c_re >> 6) << 5) + l31;
+      const bool valid = feat < ep.kvalid;
+      float w[4] = {0.f, 0.f, 0.f, 0.f};
+      float bb = 0.f;
+      if (valid) {
+        bb = ep.b0[feat];
+        for (int d = 0; d < ep.D; ++d) w[d] = ep.W0[feat * ep.D + d];
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m_w + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < M) {
+            float u = bb;
+            for (int d = 0; d < ep.D; ++d) u = __builtin_fmaf(ep.coords[(size_t)row * ep.D + d], w[d], u);
+            const size_t o1 = (size_t)row * ep.ld1;
+            const float pr = ep.i1[o1 + c_re], pi = ep.i1[o1 + c_im];
+            float gu = gabor_bwd_real(acc[i][jp][r], acc[i][jp + 1][r], u, pr, pi, ep.omega, m2s2);
+            ep.o0[(size_t)row * ep.ldu + feat] = valid ? gu : 0.f;
+          }
+        }
+    }
+  } else if constexpr (EPI == EPI_SIREN_FWD || EPI == EPI_GAUSS_FWD || EPI == EPI_RELU_FWD) {
+    constexpr int ACT = EPI - EPI_SIREN_FWD;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = n_w + 32 * j + l31;
+      const float bb = ep.bias[col];
+      const bool valid = col < ep.kvalid;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m_w + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float lin = acc[i][j][r] + bb;
+          float o = real_act_fwd<ACT>(lin, ep.omega, ep.scale);
+          if (!valid) o = 0.f;
+          if (row < M) {
+            if (ep.o0) ep.o0[(size_t)row * ep.ld0 + col] = lin;
+            ep.o1[(size_t)row * ep.ld1 + col] = o;
+          }
+        }
+    }
+  } else if constexpr (EPI == EPI_SIREN_BWD || EPI == EPI_GAUSS_BWD || EPI == EPI_RELU_BWD) {
+    constexpr int ACT = EPI - EPI_SIREN_BWD;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = n_w + 32 * j + l31;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m_w + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < M) {
+            const float lin = ep.i0[(size_t)row * ep.ld0 + col];
+            const float out = ep.i1[(size_t)row * ep.ld1 + col];
+            ep.o0[(size_t)row * ep.ld0 + col] =
+                real_act_bwd<ACT>(acc[i][j][r], lin, out, ep.omega, ep.scale);
+          }
+        }
+    }
+  } else if constexpr (EPI == EPI_GABOR2D_FWD) {
+    // wave tile = 32 rows x 128 columns = (lin_re | lin_im | sy_re | sy_im) of 32 features
+    static_assert(EPI != EPI_GABOR2D_FWD || WN == 4, "2-D Gabor needs a 128-column wave tile");
+    const int c0 = n_w + l31;                 // GEMM column of lin_re
+    const int grp = n_w >> 7;                 // feature group
+    const int feat = (grp << 5) + l31;
+    const int oc_re = (grp << 6) + l31;       // column in the P-wide output row
+    const float b_u = ep.bias[c0], b_v = ep.bias[c0 + 32], b_p = ep.bias[c0 + 64], b_q = ep.bias[c0 + 96];
+    const bool valid = feat < ep.kvalid;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m_w + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float u = acc[i][0][r] + b_u, v = acc[i][1][r] + b_v;
+        const float p = acc[i][2][r] + b_p, q = acc[i][3][r] + b_q;
+        float o_re, o_im;
+        gabor2d_fwd(u, v, p, q, ep.omega, ep.scale, o_re, o_im);
+        if (!valid) { o_re = 0.f; o_im = 0.f; }
+        if (row < M) {
+          if (ep.o0) {
+            float* L = ep.o0 + (size_t)row * ep.ld0 + c0;
+            L[0] = u; L[32] = v; L[64] = p; L[96] = q;
+          }
+          ep.o1[(size_t)row * ep.ld1 + oc_re] = o_re;
+          ep.o1[(size_t)row * ep.ld1 + oc_re + 32] = o_im;
+        }
+      }
+  } else if constexpr (EPI == EPI_GABOR2D_BWD || EPI == EPI_GABOR2D_BWD_FIRST) {
+    // C = g_out (re|im pairs, P-wide); writes g_(lin|sy) into the 2P-wide row
+    const float s2 = ep.scale * ep.scale;
+    const float m2s2 = -2.f * s2;
+#pragma unroll
+    for (int jp = 0; jp < WN; jp += 2) {
+      const int c_re = n_w + 32 * jp + l31;
+      const int grp = c_re >> 6;
+      const int feat = (grp << 5) + l31;
+      const int lc = (grp << 7) + l31;        // lin_re column in the 2P row
+      float w[4] = {0.f, 0.f, 0.f, 0.f}, wv[4] = {0.f, 0.f, 0.f, 0.f};
+      float bb = 0.f, bv = 0.f;
+      const bool valid = feat < ep.kvalid;
+      if (EPI == EPI_GABOR2D_BWD_FIRST && valid) {
+        bb = ep.b0[feat]; bv = ep.b0b[feat];
+        for (int d = 0; d < ep.D; ++d) { w[d] = ep.W0[feat * ep.D + d]; wv[d] = ep.W0b[feat * ep.D + d]; }
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m_w + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < M) {
+            const size_t o1 = (size_t)row * ep.ld1;
+            const float pr = ep.i1[o1 + c_re], pi = ep.i1[o1 + c_re + 32];
+            const float gr = acc[i][jp][r], gi = acc[i][jp + 1][r];
+            const float c_r = __builtin_fmaf(pr, gr, pi * gi);
+            const float c_i = __builtin_fmaf(pr, gi, -(pi * gr));
+            const float t = m2s2 * c_r;
+            if (EPI == EPI_GABOR2D_BWD) {
+              const float* L = ep.i0 + (size_t)row * ep.ld0 + lc;
+              const float u = L[0], v = L[32], p = L[64], q = L[96];
+              float* Gp = ep.o0 + (size_t)row * ep.ld0 + lc;
+              // g_lin = -2 s^2 P lin - j w0 c ; g_sy = -2 s^2 P sy
+              Gp[0] = __builtin_fmaf(t, u, ep.omega * c_i);
+              Gp[32] = __builtin_fmaf(t, v, -(ep.omega * c_r));
+              Gp[64] = t * p;
+              Gp[96] = t * q;
+            } else {
+              float u = bb, p = bv;
+              for (int d = 0; d < ep.D; ++d) {
+                const float x = ep.coords[(size_t)row * ep.D + d];
+                u = __builtin_fmaf(x, w[d], u);
+                p = __builtin_fmaf(x, wv[d], p);
+              }
+              // real first layer: g_u = -2 s^2 u P + w0 Im c ; g_p = -2 s^2 p P
+              float* Gp = ep.o0 + (size_t)row * (2 * ep.ldu);
+              Gp[feat] = valid ? __builtin_fmaf(t, u, ep.omega * c_i) : 0.f;
+              Gp[ep.ldu + feat] = valid ? t * p : 0.f;
+            }
+          }
+        }
+    }
+  }
+}
+
+template <int EPI, int MT, int WN>
+static hipError_t launch_nt_t(hipStream_t s, const float* A, int lda, const float* Bt, int ldb,
+                              int64_t M, int Nc, int Kd, const GemmEpiParams& ep) {
+  const int tiles_m = (int)((M + BM - 1) / BM);
+  const int tiles_n = (Nc + BN - 1) / BN;
+  const int tiles_m_pad = (tiles_m + 7) & ~7;
+  dim3 grid((unsigned)(tiles_m_pad * tiles_n));
+  hipLaunchKernelGGL((gemm_nt_kernel<EPI, MT, WN>), grid, dim3(256), 0, s, A, lda, Bt, ldb, (int)M,
+                     Nc, Kd, tiles_m, tiles_n, ep);
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_nt(hipStream_t s, int epi, const float* A, int lda, const float* Bt, int ldb,
+                          int64_t M, int Nc, int Kd, const GemmEpiParams& ep) {
+  if (M <= 0) return hipSuccess;
+  if ((Nc & 63) || (Kd & 31) || (lda & 3) || (ldb & 3) || M > 0x7fffff00LL) return hipErrorInvalidValue;
+  switch (epi) {
+    case EPI_STORE: return launch_nt_t<EPI_STORE, 2, 2>(s, A, lda, Bt, ldb, M, Nc, Kd, ep);
+    case EPI_GABOR_FWD: return launch_nt_t<EPI_GABOR_FWD, 2, 2>(s, A, lda, Bt, ldb, M, Nc, Kd, ep);
+    case EPI_GABOR_BWD: return launch_nt_t<EPI_GABOR_BWD, 2, 2>(s, A, lda, Bt, ldb, M, Nc, Kd, ep);
+    case EPI_GABOR_BWD_FIRST: return launch_nt_t<EPI_GABOR_BWD_FIRST, 2, 2>(s, A, lda, Bt, ldb, M, Nc, Kd, ep);
+    case EPI_SIREN_FWD: return launch_nt_t<EPI_SIREN_FWD, 2, 2>(s, A, lda, Bt, ldb, M, Nc, Kd, ep);
+    case EPI_GAUSS_FWD: return launch_nt_t<EPI_GAUSS_FWD, 2, 2>(s, A, lda, Bt, ldb, M, Nc, Kd, ep);
+    case EPI_RELU_FWD: return launch_nt_t<EPI_RELU_FWD, 2, 2>(s, A, lda, Bt, ldb, M, Nc, Kd, ep);
+    case EPI_SIREN_BWD: return launch_nt_t<EPI_SIREN_BWD, 2, 2>(s, A, lda, Bt, ldb, M, Nc, Kd, ep);
+    case EPI_GAUSS_BWD: return launch_nt_t<EPI_GAUSS_BWD, 2, 2>(s, A, lda, Bt, ldb, M, Nc, Kd, ep);
+    case EPI_RELU_BWD: return launch_nt_t<EPI_RELU_BWD, 2, 2>(s, A, lda, Bt, ldb, M, Nc, Kd, ep);
+    case EPI_GABOR2D_FWD:
+      if (Nc & 127) return hipErrorInvalidValue;
+      return launch_nt_t<EPI_GABOR2D_FWD, 1, 4>(s, A, lda, Bt, ldb, M, Nc, Kd, ep);
+    case EPI_GABOR2D_BWD: return launch_nt_t<EPI_GABOR2D_BWD, 2, 2>(s, A, lda, Bt, ldb, M, Nc, Kd, ep);
+    case EPI_GABOR2D_BWD_FIRST: return launch_nt_t<EPI_GABOR2D_BWD_FIRST, 2, 2>(s, A, lda, Bt, ldb, M, Nc, Kd, ep);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// TN GEMM: weight gradient.  slab[split][Pm][Pn] = sum over the split's rows of
+// G[row][m] * Z[row][n];  bslab[split][m] = sum of G[row][m]  (bias gradient).
+// ---------------------------------------------------------------------------
+#define TK 32   // rows (reduction steps) per LDS tile
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(
+    const float* __restrict__ G, int ldg, const float* __restrict__ Z, int ldz, long long n,
+    int Pm, int Pn, int tiles_n, long long chunk, float* __restrict__ slab,
+    float* __restrict__ bslab) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TK * 128];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int split = blockIdx.y;
+  const int m_base = tm * 128, n_base = tn * 128;
+  const long long row0 = (long long)split * chunk;
+  long long row1 = row0 + chunk;
+  if (row1 > n) row1 = n;
+
+  // loader: 32 threads x float4 per 128-float row, 8 rows per pass, 4 passes
+  const int lrow = tid >> 5;
+  const int lc4 = (tid & 31) * 4;
+  int gcol = m_base + lc4; if (gcol > Pm - 4) gcol = Pm - 4;
+  int zcol = n_base + lc4; if (zcol > Pn - 4) zcol = Pn - 4;
+  const int st_off = lrow * 128 + lc4;
+
+  const bool live_m = (m_base + wave_m * 64) < Pm;
+  const bool live_n = (n_base + wave_n * 64) < Pn;
+  const bool wave_live = live_m && live_n;
+  const bool do_bias = (bslab != nullptr) && (tn == 0) && (wave_n == 0) && live_m;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[2] = {0.f, 0.f};
+
+  const long long nrows = row1 > row0 ? row1 - row0 : 0;
+  const int nk = (int)((nrows + TK - 1) / TK);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  f32x4 rg[4], rz[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const long long row = row0 + (long long)kt * TK + lrow + 8 * p;
+      if (row < row1) {
+        rg[p] = *reinterpret_cast<const f32x4*>(G + (size_t)row * ldg + gcol);
+        rz[p] = *reinterpret_cast<const f32x4*>(Z + (size_t)row * ldz + zcol);
+      } else {
+        rg[p] = zero4;
+        rz[p] = zero4;
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* Gs = smem + buf * (2 * TK * 128);
+    float* Zs = Gs + TK * 128;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *reinterpret_cast<f32x4*>(&Gs[st_off + 8 * p * 128]) = rg[p];
+      *reinterpret_cast<f32x4*>(&Zs[st_off + 8 * p * 128]) = rz[p];
+    }
+  };
+
+  if (nk > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+
+  const int g_rd = h * 128 + wave_m * 64 + l31;
+  const int z_rd = h * 128 + wave_n * 64 + l31;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const bool more = (kt + 1) < nk;
+    if (more) gload(kt + 1);
+    const float* Gs = smem + buf * (2 * TK * 128);
+    const float* Zs = Gs + TK * 128;
+    if (wave_live || do_bias) {
+#pragma unroll
+      for (int kp = 0; kp < TK / 2; ++kp) {
+        const float a0 = Gs[g_rd + kp * 256];
+        const float a1 = Gs[g_rd + kp * 256 + 32];
+        if (do_bias) { bsum[0] += a0; bsum[1] += a1; }
+        if (wave_live) {
+          const float b0 = Zs[z_rd + kp * 256];
+          const float b1 = Zs[z_rd + kp * 256 + 32];
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+      }
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float v = bsum[i] + __shfl_xor(bsum[i], 32);
+      const int m = m_base + wave_m * 64 + 32 * i + l31;
+      if (h == 0 && m < Pm) bslab[(size_t)split * Pm + m] = v;
+    }
+  }
+  if (!wave_live) return;
+  float* out = slab + (size_t)split * Pm * Pn;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n_base + wave_n * 64 + 32 * j + l31;
+      if (col < Pn) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m_base + wave_m * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < Pm) out[(size_t)m * Pn + col] = acc[i][j][r];
+        }
+      }
+    }
+}
+
+int gemm_tn_splits(int64_t n, int Pm, int Pn, int max_splits) {
+  const int tiles = ((Pm + 127) / 128) * ((Pn + 127) / 128);
+  int s = (512 + tiles - 1) / tiles;          // ~2 workgroups per CU
+  int64_t by_rows = (n + 255) / 256;          // at least 256 rows per split
+  if (by_rows < 1) by_rows = 1;
+  if (s > by_rows) s = (int)by_rows;
+  if (s > max_splits) s = max_splits;
+  if (s < 1) s = 1;
+  return s;
+}
+
+hipError_t launch_gemm_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz,
+                          int64_t n, int Pm, int Pn, int splits, float* slab, float* bslab) {
+  if ((Pm & 3) || (Pn & 3) || (ldg & 3) || (ldz & 3) || splits < 1) return hipErrorInvalidValue;
+  const int tiles_m = (Pm + 127) / 128, tiles_n = (Pn + 127) / 128;
+  long long chunk = (n + splits - 1) / splits;
+  chunk = (chunk + TK - 1) / TK * TK;
+  if (chunk < TK) chunk = TK;
+  dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splits);
+  hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, s, G, ldg, Z, ldz, (long long)n, Pm, Pn,
+                     tiles_n, chunk, slab, bslab);
+  return hipGetLastError();
+}

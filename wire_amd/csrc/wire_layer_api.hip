@@ -1,0 +1,176 @@
+// wire_layer_api.hip -- per-layer entry points of the C ABI:
+// ComplexGaborLayer.forward / its backward and the final complex Linear + .real
+// on native (interleaved complex64) tensors.  These serve `model.net[i](x)`
+// (reference modules/utils.py:246-252) and standalone layers; the training hot
+// path is wire_mlp_fwd / wire_mlp_bwd, which never leaves the blocked layout.
+// The backward recomputes the layer's forward from x (one extra GEMM) instead
+// of asking the caller to keep lin/act in a private layout.
+#include <hip/hip_runtime.h>
+
+#include "../../include/wire_hip.h"
+#include "wire_gemm.h"
+#include "wire_point.h"
+
+extern int wire_fail_(int code, const char* msg);   // wire_api.hip
+
+namespace {
+inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+inline int64_t rup64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+struct LayerWs {
+  int Pin, Pout, S;
+  int64_t xb, lin, out, gact, glin, gxb, gu, btf, btd, bias, slab, bslab, fpw, fpb, crp, wf, bfr, total;
+};
+LayerWs layer_ws(int64_t n, int in, int out) {
+  LayerWs w{};
+  w.Pin = rup(2 * in, 64);
+  w.Pout = rup(2 * out, 64);
+  const int Pmax = w.Pin > w.Pout ? w.Pin : w.Pout;
+  w.S = gemm_tn_splits(n, w.Pout, w.Pin, 64);
+  int64_t off = 0;
+  auto take = [&](int64_t cnt) { int64_t o = off; off += rup64(cnt, 64); return o; };
+  w.xb = take(n * w.Pin);
+  w.lin = take(n * w.Pout);
+  w.out = take(n * w.Pout);
+  w.gact = take(n * w.Pout);
+  w.glin = take(n * w.Pout);
+  w.gxb = take(n * w.Pin);
+  w.gu = take(n * (w.Pout / 2));
+  w.btf = take((int64_t)w.Pout * w.Pin);
+  w.btd = take((int64_t)w.Pout * w.Pin);
+  w.bias = take(w.Pout);
+  w.slab = take((int64_t)w.S * w.Pout * w.Pin);
+  w.bslab = take((int64_t)w.S * w.Pout);
+  w.fpw = take((int64_t)final_bwd_blocks(n) * 8 * Pmax);
+  w.fpb = take((int64_t)final_bwd_blocks(n) * 8);
+  w.crp = take((int64_t)colreduce_blocks(n) * (w.Pout / 2) * 5);
+  w.wf = take((int64_t)8 * Pmax);
+  w.bfr = take(64);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+#define LCHK(expr)                                                   \
+  do {                                                               \
+    hipError_t e_ = (expr);                                          \
+    if (e_ != hipSuccess) return wire_fail_(WIRE_ERR_HIP, hipGetErrorString(e_)); \
+  } while (0)
+
+extern "C" int64_t wire_layer_ws_bytes(int64_t n, int in_features, int out_features) {
+  if (n < 0 || in_features < 1 || out_features < 1) return wire_fail_(WIRE_ERR_ARG, "bad layer shape");
+  return layer_ws(n, in_features, out_features).total * 4 + 256;
+}
+
+// forward into the workspace (lin, out blocked).  Shared by fwd and bwd.
+static int layer_forward_ws(hipStream_t s, const LayerWs& w, float* W_, const void* x, const void* Wt,
+                            const void* b, float omega0, float scale0, int64_t n, int in, int out,
+                            int is_first) {
+  if (is_first) {
+    if (in > 4) return wire_fail_(WIRE_ERR_ARG, "is_first layers support in_features <= 4");
+    LCHK(launch_first_fwd(s, NK_WIRE, (const float*)x, n, in, (const float*)Wt, (const float*)b,
+                          nullptr, nullptr, out, w.Pout, omega0, scale0, nullptr, W_ + w.out));
+    return WIRE_OK;
+  }
+  LCHK(launch_c64_to_blocked(s, (const float*)x, n, in, w.Pin, W_ + w.xb));
+  LCHK(launch_pack_hidden(s, NK_WIRE, (const float*)Wt, (const float*)b, nullptr, nullptr, out, in,
+                          w.Pout, w.Pin, W_ + w.btf, W_ + w.btd, W_ + w.bias));
+  GemmEpiParams ep;
+  ep.bias = W_ + w.bias; ep.o0 = W_ + w.lin; ep.o1 = W_ + w.out; ep.ld0 = w.Pout; ep.ld1 = w.Pout;
+  ep.omega = omega0; ep.scale = scale0; ep.kvalid = out;
+  LCHK(launch_gemm_nt(s, EPI_GABOR_FWD, W_ + w.xb, w.Pin, W_ + w.btf, w.Pin, n, w.Pout, w.Pin, ep));
+  return WIRE_OK;
+}
+
+extern "C" int wire_gabor_fwd(void* stream, const void* x, const void* W, const void* b,
+                              float omega0, float scale0, int64_t n, int in_features,
+                              int out_features, int is_first, void* lin_out, void* act_out,
+                              void* ws, int64_t ws_bytes) {
+  if (n < 0 || in_features < 1 || out_features < 1 || !x || !W || !b || !act_out || !ws)
+    return wire_fail_(WIRE_ERR_ARG, "bad argument to wire_gabor_fwd");
+  if (lin_out) return wire_fail_(WIRE_ERR_ARG, "lin_out is not supported in ABI v1 (pass NULL)");
+  if (n == 0) return WIRE_OK;
+  const LayerWs w = layer_ws(n, in_features, out_features);
+  if (ws_bytes < w.total * 4) return wire_fail_(WIRE_ERR_SIZE, "layer workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* W_ = (float*)ws;
+  if (int rc = layer_forward_ws(s, w, W_, x, W, b, omega0, scale0, n, in_features, out_features, is_first))
+    return rc;
+  LCHK(launch_blocked_to_c64(s, W_ + w.out, n, out_features, w.Pout, (float*)act_out));
+  return WIRE_OK;
+}
+
+extern "C" int wire_gabor_bwd(void* stream, const void* g_act, const void* x, const void* W,
+                              const void* b, float omega0, float scale0, int64_t n,
+                              int in_features, int out_features, int is_first, void* g_x,
+                              void* g_W, void* g_b, void* ws, int64_t ws_bytes) {
+  if (n <= 0 || in_features < 1 || out_features < 1 || !g_act || !x || !W || !b || !g_W || !g_b || !ws)
+    return wire_fail_(WIRE_ERR_ARG, "bad argument to wire_gabor_bwd");
+  const LayerWs w = layer_ws(n, in_features, out_features);
+  if (ws_bytes < w.total * 4) return wire_fail_(WIRE_ERR_SIZE, "layer workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* W_ = (float*)ws;
+  if (int rc = layer_forward_ws(s, w, W_, x, W, b, omega0, scale0, n, in_features, out_features, is_first))
+    return rc;
+  LCHK(launch_c64_to_blocked(s, (const float*)g_act, n, out_features, w.Pout, W_ + w.gact));
+  if (is_first) {
+    const int ldu = w.Pout / 2;
+    LCHK(launch_gabor_bwd_first_point(s, W_ + w.gact, W_ + w.out, (const float*)x, in_features,
+                                      (const float*)W, (const float*)b, n, out_features, w.Pout,
+                                      omega0, scale0, W_ + w.gu, ldu));
+    LCHK(launch_colreduce(s, W_ + w.gu, ldu, out_features, (const float*)x, in_features, n,
+                          W_ + w.crp, (float*)g_W, (float*)g_b));
+    return WIRE_OK;
+  }
+  LCHK(launch_gabor_bwd_point(s, W_ + w.gact, W_ + w.lin, W_ + w.out, n, w.Pout, omega0, scale0,
+                              W_ + w.glin));
+  if (g_x) {
+    GemmEpiParams ep; ep.o0 = W_ + w.gxb; ep.ld0 = w.Pin;
+    LCHK(launch_gemm_nt(s, EPI_STORE, W_ + w.glin, w.Pout, W_ + w.btd, w.Pout, n, w.Pin, w.Pout, ep));
+    LCHK(launch_blocked_to_c64(s, W_ + w.gxb, n, in_features, w.Pin, (float*)g_x));
+  }
+  LCHK(launch_gemm_tn(s, W_ + w.glin, w.Pout, W_ + w.xb, w.Pin, n, w.Pout, w.Pin, w.S, W_ + w.slab,
+                      W_ + w.bslab));
+  LCHK(launch_wgrad_reduce(s, NK_WIRE, W_ + w.slab, W_ + w.bslab, w.S, out_features, in_features,
+                           w.Pout, w.Pin, (float*)g_W, (float*)g_b, nullptr, nullptr));
+  return WIRE_OK;
+}
+
+extern "C" int wire_final_fwd(void* stream, const void* z, const void* Wf, const void* bf, int64_t n,
+                              int in_features, int out_features, float* y, void* ws,
+                              int64_t ws_bytes) {
+  if (n < 0 || in_features < 1 || out_features < 1 || out_features > 8 || !z || !Wf || !bf || !y || !ws)
+    return wire_fail_(WIRE_ERR_ARG, "bad argument to wire_final_fwd");
+  if (n == 0) return WIRE_OK;
+  const LayerWs w = layer_ws(n, in_features, out_features);
+  if (ws_bytes < w.total * 4) return wire_fail_(WIRE_ERR_SIZE, "layer workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* W_ = (float*)ws;
+  LCHK(launch_c64_to_blocked(s, (const float*)z, n, in_features, w.Pin, W_ + w.xb));
+  LCHK(launch_pack_final(s, NK_WIRE, (const float*)Wf, (const float*)bf, in_features, w.Pin,
+                         out_features, W_ + w.wf, W_ + w.bfr));
+  LCHK(launch_final_fwd(s, W_ + w.xb, n, w.Pin, out_features, W_ + w.wf, W_ + w.bfr, y));
+  return WIRE_OK;
+}
+
+extern "C" int wire_final_bwd(void* stream, const float* g_y, const void* z, const void* Wf,
+                              int64_t n, int in_features, int out_features, void* g_z, void* g_Wf,
+                              void* g_bf, void* ws, int64_t ws_bytes) {
+  if (n <= 0 || in_features < 1 || out_features < 1 || out_features > 8 || !g_y || !z || !Wf ||
+      !g_Wf || !g_bf || !ws)
+    return wire_fail_(WIRE_ERR_ARG, "bad argument to wire_final_bwd");
+  const LayerWs w = layer_ws(n, in_features, out_features);
+  if (ws_bytes < w.total * 4) return wire_fail_(WIRE_ERR_SIZE, "layer workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* W_ = (float*)ws;
+  LCHK(launch_c64_to_blocked(s, (const float*)z, n, in_features, w.Pin, W_ + w.xb));
+  // bias pointer is irrelevant for the gradient; reuse Wf so the kernel reads valid memory
+  LCHK(launch_pack_final(s, NK_WIRE, (const float*)Wf, (const float*)Wf, in_features, w.Pin,
+                         out_features, W_ + w.wf, W_ + w.bfr));
+  LCHK(launch_final_bwd(s, NK_WIRE, 1, g_y, n, out_features, W_ + w.wf, nullptr, W_ + w.xb,
+                        in_features, w.Pin, 0.f, 0.f, W_ + w.gxb, W_ + w.fpw, W_ + w.fpb));
+  LCHK(launch_final_reduce(s, NK_WIRE, W_ + w.fpw, W_ + w.fpb, final_bwd_blocks(n), out_features,
+                           in_features, w.Pin, (float*)g_Wf, (float*)g_bf));
+  if (g_z) LCHK(launch_blocked_to_c64(s, W_ + w.gxb, n, in_features, w.Pin, (float*)g_z));
+  return WIRE_OK;
+}

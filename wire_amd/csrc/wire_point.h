@@ -1,0 +1,74 @@
+// wire_point.h -- launchers of the bandwidth-bound kernels around the GEMMs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { NK_WIRE = 0, NK_WIRE2D = 1, NK_SIREN = 2, NK_GAUSS = 3, NK_RELU = 4 };
+
+// ---- weight packing (native nn.Parameter layout -> padded real-expanded image)
+hipError_t launch_pack_hidden(hipStream_t s, int kind, const float* W, const float* b,
+                              const float* V, const float* c, int K, int Kin, int P, int Pin,
+                              float* Bt_fwd, float* Bt_dgrad, float* bias);
+hipError_t launch_pack_final(hipStream_t s, int kind, const float* Wf, const float* bf, int K,
+                             int P, int O, float* wf, float* bfr);
+
+// ---- first layer (D <= 4 inputs): elementwise, VALU/HBM-write bound
+// out [n][P] blocked; lin (optional): real nets [n][P]; wire2d [n][2*Kp] (u | p)
+hipError_t launch_first_fwd(hipStream_t s, int kind, const float* coords, int64_t n, int D,
+                            const float* W0, const float* b0, const float* V0, const float* c0,
+                            int K, int P, float omega, float scale, float* lin, float* out);
+
+// ---- final linear: y[n][O] = z[n][P] . wf[O][P] + bf
+hipError_t launch_final_fwd(hipStream_t s, const float* z, int64_t n, int P, int O,
+                            const float* wf, const float* bfr, float* y);
+
+// ---- final-layer backward fused with the last hidden activation gradient.
+// g_out = g_y * wf; g_lin = act'(g_out; lin, out).  Also per-block partials of
+// g_wf[o][c] = sum_n g_y[n][o] out[n][c] and of sum_n g_y[n][o].
+// raw != 0: skip the activation gradient and write g_out itself (per-layer API).
+int final_bwd_blocks(int64_t n);
+hipError_t launch_final_bwd(hipStream_t s, int kind, int raw, const float* g_y, int64_t n, int O,
+                            const float* wf, const float* lin, const float* out, int K, int P,
+                            float omega, float scale, float* g_lin, float* part_w,
+                            float* part_b);
+hipError_t launch_final_reduce(hipStream_t s, int kind, const float* part_w, const float* part_b,
+                               int nblk, int O, int K, int P, float* gWf, float* gbf);
+
+// ---- weight-gradient slab reduction: slab[S][Pm][Pn] (+ bslab[S][Pm]) -> native grads
+hipError_t launch_wgrad_reduce(hipStream_t s, int kind, const float* slab, const float* bslab,
+                               int S, int K, int Kin, int Pm, int Pn, float* gW, float* gb,
+                               float* gV, float* gc);
+
+// ---- first-layer weight gradient: g_W0[c][d] = sum_n G[n][c] x[n][d], g_b0[c] = sum_n G[n][c]
+int colreduce_blocks(int64_t n);
+hipError_t launch_colreduce(hipStream_t s, const float* G, int ldg, int C, const float* x, int D,
+                            int64_t n, float* partial, float* gW0, float* gb0);
+
+// ---- layout conversion for the per-layer API
+hipError_t launch_c64_to_blocked(hipStream_t s, const float* src, int64_t n, int K, int P, float* dst);
+hipError_t launch_blocked_to_c64(hipStream_t s, const float* src, int64_t n, int K, int P, float* dst);
+// real [n][K] <-> padded [n][P]
+hipError_t launch_pad_rows(hipStream_t s, const float* src, int64_t n, int K, int P, float* dst);
+hipError_t launch_unpad_rows(hipStream_t s, const float* src, int64_t n, int K, int P, float* dst);
+
+// ---- elementwise Gabor gradient for the per-layer API
+hipError_t launch_gabor_bwd_point(hipStream_t s, const float* g, const float* lin, const float* out,
+                                  int64_t n, int P, float omega, float scale, float* g_lin);
+hipError_t launch_gabor_bwd_first_point(hipStream_t s, const float* g, const float* out,
+                                        const float* coords, int D, const float* W0, const float* b0,
+                                        int64_t n, int K, int P, float omega, float scale, float* g_u,
+                                        int ldu);
+
+// ---- positional encoding (modules/relu.py:62-75) into a [n][Pin] padded row
+hipError_t launch_posenc(hipStream_t s, const float* coords, int64_t n, int D, int F, int Pin,
+                         float* dst);
+
+// ---- training glue
+hipError_t launch_coords(hipStream_t s, const int64_t* idx, int64_t first, int64_t n,
+                         const float* tx, int W, const float* ty, int H, const float* tz, int T,
+                         float* coords);
+hipError_t launch_mse_grad(hipStream_t s, const float* y, const float* target, const int64_t* idx,
+                           int64_t first, int64_t n, int O, float weight, float* g_y,
+                           float* loss_out, float* rec, float* partial);
+hipError_t launch_adam(hipStream_t s, float* p, const float* g, float* m, float* v, int64_t count,
+                       float step_size, float beta1, float beta2, float eps, float inv_sqrt_bc2);

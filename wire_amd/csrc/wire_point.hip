@@ -1,0 +1,766 @@
+// wire_point.hip -- the bandwidth/VALU-bound kernels around the MFMA GEMMs:
+// weight packing, first layer (D <= 4 inputs), final linear (O <= 8 outputs)
+// forward / backward, deterministic slab reductions, layout conversion and the
+// training-step glue (coordinate generation, MSE gradient, flat Adam).
+//
+// All of them move each activation byte at most once and keep 128-byte
+// (32 lanes x 4 B) or 16-byte-per-lane accesses; none needs MFMA.
+#include "wire_dev.h"
+#include "wire_point.h"
+
+#define MAXO 8
+
+static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// ===========================================================================
+// packing
+// ===========================================================================
+// Hidden layer.  GEMM column j (output) and reduction index k (input) are in
+// blocked-planar order.  Complex layer (modules/wire.py:89, F.linear without
+// conjugation):  lin = z W^T  <=>  real image
+//     [ (o,re),(i,re) ] =  W_re   [ (o,re),(i,im) ] = -W_im
+//     [ (o,im),(i,re) ] =  W_im   [ (o,im),(i,im) ] =  W_re
+// The data-gradient GEMM g_z = g_lin conj(W) uses exactly the transposed image.
+__global__ void pack_hidden_kernel(int kind, const float* __restrict__ W, const float* __restrict__ b,
+                                   const float* __restrict__ V, const float* __restrict__ c, int K,
+                                   int Kin, int P, int Pin, int Nc, float* __restrict__ Bt_fwd,
+                                   float* __restrict__ Bt_dgrad, float* __restrict__ bias) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;   // input (reduction) index
+  const int j = blockIdx.y;                              // GEMM output column
+  if (k >= Pin) return;
+  float val = 0.f, bv = 0.f;
+  if (kind == NK_WIRE || kind == NK_WIRE2D) {
+    int o, part;
+    const float* Wm = W;
+    const float* bm = b;
+    if (kind == NK_WIRE) {
+      blk_decode(j, o, part);
+    } else {
+      const int sub = (j >> 5) & 3;
+      o = ((j >> 7) << 5) + (j & 31);
+      part = sub & 1;
+      if (sub >= 2) { Wm = V; bm = c; }
+    }
+    int i, ipart;
+    blk_decode(k, i, ipart);
+    if (o < K) {
+      bv = bm[2 * o + part];
+      if (i < Kin) {
+        const float wr = Wm[((size_t)o * Kin + i) * 2];
+        const float wi = Wm[((size_t)o * Kin + i) * 2 + 1];
+        val = part == 0 ? (ipart == 0 ? wr : -wi) : (ipart == 0 ? wi : wr);
+      }
+    }
+  } else {
+    if (j < K) {
+      bv = b[j];
+      if (k < Kin) val = W[(size_t)j * Kin + k];
+    }
+  }
+  Bt_fwd[(size_t)j * Pin + k] = val;
+  Bt_dgrad[(size_t)k * Nc + j] = val;
+  if (k == 0) bias[j] = bv;
+}
+
+hipError_t launch_pack_hidden(hipStream_t s, int kind, const float* W, const float* b,
+                              const float* V, const float* c, int K, int Kin, int P, int Pin,
+                              float* Bt_fwd, float* Bt_dgrad, float* bias) {
+  const int Nc = (kind == NK_WIRE2D) ? 2 * P : P;
+  dim3 grid(cdiv(Pin, 128), (unsigned)Nc);
+  hipLaunchKernelGGL(pack_hidden_kernel, grid, dim3(128), 0, s, kind, W, b, V, c, K, Kin, P, Pin,
+                     Nc, Bt_fwd, Bt_dgrad, bias);
+  return hipGetLastError();
+}
+
+// final nn.Linear(K, O, cfloat) + .real (modules/wire.py:156-157,164-165):
+//   y = z_re W_re^T - z_im W_im^T + Re b
+__global__ void pack_final_kernel(int kind, const float* __restrict__ Wf, const float* __restrict__ bf,
+                                  int K, int P, int O, float* __restrict__ wf, float* __restrict__ bfr) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int o = blockIdx.y;
+  if (c >= P) return;
+  float val = 0.f;
+  if (kind == NK_WIRE || kind == NK_WIRE2D) {
+    int i, part;
+    blk_decode(c, i, part);
+    if (i < K) {
+      const float w = Wf[((size_t)o * K + i) * 2 + part];
+      val = part == 0 ? w : -w;
+    }
+    if (c == 0) bfr[o] = bf[2 * o];
+  } else {
+    if (c < K) val = Wf[(size_t)o * K + c];
+    if (c == 0) bfr[o] = bf[o];
+  }
+  wf[(size_t)o * P + c] = val;
+}
+
+hipError_t launch_pack_final(hipStream_t s, int kind, const float* Wf, const float* bf, int K,
+                             int P, int O, float* wf, float* bfr) {
+  dim3 grid(cdiv(P, 128), (unsigned)O);
+  hipLaunchKernelGGL(pack_final_kernel, grid, dim3(128), 0, s, kind, Wf, bf, K, P, O, wf, bfr);
+  return hipGetLastError();
+}
+
+// ===========================================================================
+// first layer: coords [n][D] (D <= 4) -> activations.  One thread per output
+// feature, 64 rows per block: W0 row in registers, coordinates broadcast.
+// ===========================================================================
+#define FIRST_ROWS 64
+template <int KIND>
+__global__ void first_fwd_kernel(const float* __restrict__ coords, long long n, int D,
+                                 const float* __restrict__ W0, const float* __restrict__ b0,
+                                 const float* __restrict__ V0, const float* __restrict__ c0, int K,
+                                 int P, float omega, float scale, float* __restrict__ lin,
+                                 float* __restrict__ out) {
+  constexpr bool cplx = (KIND == NK_WIRE || KIND == NK_WIRE2D);
+  const int nfeat = cplx ? (P >> 1) : P;
+  const int f = blockIdx.y * blockDim.x + threadIdx.x;
+  if (f >= nfeat) return;
+  const bool valid = f < K;
+  float w[4] = {0.f, 0.f, 0.f, 0.f}, wv[4] = {0.f, 0.f, 0.f, 0.f};
+  float bb = 0.f, bv = 0.f;
+  if (valid) {
+    bb = b0[f];
+    for (int d = 0; d < D; ++d) w[d] = W0[f * D + d];
+    if (KIND == NK_WIRE2D) {
+      bv = c0[f];
+      for (int d = 0; d < D; ++d) wv[d] = V0[f * D + d];
+    }
+  }
+  const long long r0 = (long long)blockIdx.x * FIRST_ROWS;
+  long long r1 = r0 + FIRST_ROWS;
+  if (r1 > n) r1 = n;
+  const int c_re = cplx ? blk_col(f, 0) : f;
+  for (long long row = r0; row < r1; ++row) {
+    float u = bb, p = bv;
+    for (int d = 0; d < D; ++d) {
+      const float x = coords[row * D + d];
+      u = __builtin_fmaf(x, w[d], u);
+      if (KIND == NK_WIRE2D) p = __builtin_fmaf(x, wv[d], p);
+    }
+    if (KIND == NK_WIRE) {
+      float o_re, o_im;
+      gabor_fwd_real(u, omega, scale, o_re, o_im);
+      out[row * P + c_re] = valid ? o_re : 0.f;
+      out[row * P + c_re + 32] = valid ? o_im : 0.f;
+    } else if (KIND == NK_WIRE2D) {
+      float o_re, o_im;
+      gabor2d_fwd(u, 0.f, p, 0.f, omega, scale, o_re, o_im);
+      out[row * P + c_re] = valid ? o_re : 0.f;
+      out[row * P + c_re + 32] = valid ? o_im : 0.f;
+    } else {
+      constexpr int ACT = KIND - NK_SIREN;
+      const float o = real_act_fwd<ACT < 0 ? 0 : ACT>(u, omega, scale);
+      if (lin) lin[row * P + f] = valid ? u : 0.f;
+      out[row * P + f] = valid ? o : 0.f;
+    }
+  }
+}
+
+hipError_t launch_first_fwd(hipStream_t s, int kind, const float* coords, int64_t n, int D,
+                            const float* W0, const float* b0, const float* V0, const float* c0,
+                            int K, int P, float omega, float scale, float* lin, float* out) {
+  if (n <= 0) return hipSuccess;
+  if (D > 4) return hipErrorInvalidValue;
+  const bool cplx = (kind == NK_WIRE || kind == NK_WIRE2D);
+  const int nfeat = cplx ? P / 2 : P;
+  const int bx = nfeat >= 256 ? 256 : ((nfeat + 63) / 64) * 64;
+  dim3 grid(cdiv(n, FIRST_ROWS), cdiv(nfeat, bx));
+#define FIRST_LAUNCH(KK)                                                                       \
+  hipLaunchKernelGGL(first_fwd_kernel<KK>, grid, dim3(bx), 0, s, coords, (long long)n, D, W0, b0, \
+                     V0, c0, K, P, omega, scale, lin, out)
+  switch (kind) {
+    case NK_WIRE: FIRST_LAUNCH(NK_WIRE); break;
+    case NK_WIRE2D: FIRST_LAUNCH(NK_WIRE2D); break;
+    case NK_SIREN: FIRST_LAUNCH(NK_SIREN); break;
+    case NK_GAUSS: FIRST_LAUNCH(NK_GAUSS); break;
+    case NK_RELU: FIRST_LAUNCH(NK_RELU); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef FIRST_LAUNCH
+  return hipGetLastError();
+}
+
+// ===========================================================================
+// final linear forward: one wave per row, wf staged in LDS, butterfly reduce.
+// ===========================================================================
+__global__ __launch_bounds__(256) void final_fwd_kernel(const float* __restrict__ z, long long n,
+                                                        int P, int O, const float* __restrict__ wf,
+                                                        const float* __restrict__ bfr,
+                                                        float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float swf[];   // [O][P]
+  for (int i = threadIdx.x; i < O * P; i += blockDim.x) swf[i] = wf[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const long long wstride = (long long)gridDim.x * 4;
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < n; row += wstride) {
+    float acc[MAXO];
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) acc[o] = 0.f;
+    const float* zr = z + row * P;
+    for (int c = lane * 4; c < P; c += 256) {
+      const f32x4 zv = *reinterpret_cast<const f32x4*>(zr + c);
+#pragma unroll
+      for (int o = 0; o < MAXO; ++o)
+        if (o < O) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(&swf[o * P + c]);
+          acc[o] += zv[0] * wv[0] + zv[1] * wv[1] + zv[2] * wv[2] + zv[3] * wv[3];
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o)
+      if (o < O) {
+        float v = acc[o];
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft);
+        if (lane == o) y[row * O + o] = v + bfr[o];
+      }
+  }
+}
+
+hipError_t launch_final_fwd(hipStream_t s, const float* z, int64_t n, int P, int O,
+                            const float* wf, const float* bfr, float* y) {
+  if (n <= 0) return hipSuccess;
+  if (O > MAXO || (P & 3)) return hipErrorInvalidValue;
+  unsigned grid = cdiv(n, 4);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(final_fwd_kernel, dim3(grid), dim3(256), (size_t)O * P * sizeof(float), s, z,
+                     (long long)n, P, O, wf, bfr, y);
+  return hipGetLastError();
+}
+
+// ===========================================================================
+// final linear backward + last hidden activation gradient.
+// ===========================================================================
+#define FB_ROWS 256
+int final_bwd_blocks(int64_t n) { return (int)((n + FB_ROWS - 1) / FB_ROWS); }
+
+template <int KIND, bool RAW>
+__global__ __launch_bounds__(256) void final_bwd_kernel(
+    const float* __restrict__ g_y, long long n, int O, const float* __restrict__ wf,
+    const float* __restrict__ lin, const float* __restrict__ out, int K, int P, float omega,
+    float scale, float* __restrict__ g_lin, float* __restrict__ part_w,
+    float* __restrict__ part_b) {
+  constexpr bool cplx = (KIND == NK_WIRE || KIND == NK_WIRE2D);
+  __shared__ float sgy[FB_ROWS * MAXO];
+  const long long r0 = (long long)blockIdx.x * FB_ROWS;
+  long long r1 = r0 + FB_ROWS;
+  if (r1 > n) r1 = n;
+  const int nr = (int)(r1 - r0);
+  for (int i = threadIdx.x; i < nr * O; i += blockDim.x) sgy[i] = g_y[r0 * O + i];
+  __syncthreads();
+
+  const int nfeat = cplx ? (P >> 1) : P;
+  const int f = blockIdx.y * blockDim.x + threadIdx.x;
+  if (f < nfeat) {
+    const int c0 = cplx ? blk_col(f, 0) : f;
+    float w0[MAXO], w1[MAXO], a0[MAXO], a1[MAXO];
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) {
+      w0[o] = 0.f; w1[o] = 0.f; a0[o] = 0.f; a1[o] = 0.f;
+      if (o < O) {
+        w0[o] = wf[(size_t)o * P + c0];
+        if (cplx) w1[o] = wf[(size_t)o * P + c0 + 32];
+      }
+    }
+    const float m2s2 = -2.f * scale * scale;
+    const int Pl = (KIND == NK_WIRE2D) ? 2 * P : P;
+    const int lc = (KIND == NK_WIRE2D) ? (((f >> 5) << 7) + (f & 31)) : c0;
+    for (int r = 0; r < nr; ++r) {
+      const long long row = r0 + r;
+      float gr = 0.f, gi = 0.f;
+#pragma unroll
+      for (int o = 0; o < MAXO; ++o)
+        if (o < O) {
+          const float g = sgy[r * O + o];
+          gr = __builtin_fmaf(g, w0[o], gr);
+          if (cplx) gi = __builtin_fmaf(g, w1[o], gi);
+        }
+      const float pr = out[row * P + c0];
+      const float pi = cplx ? out[row * P + c0 + 32] : 0.f;
+#pragma unroll
+      for (int o = 0; o < MAXO; ++o)
+        if (o < O) {
+          const float g = sgy[r * O + o];
+          a0[o] = __builtin_fmaf(g, pr, a0[o]);
+          if (cplx) a1[o] = __builtin_fmaf(g, pi, a1[o]);
+        }
+      if (RAW) {
+        g_lin[row * P + c0] = gr;
+        if (cplx) g_lin[row * P + c0 + 32] = gi;
+      } else if (KIND == NK_WIRE) {
+        const float u = lin[row * P + c0], v = lin[row * P + c0 + 32];
+        float gl_re, gl_im;
+        gabor_bwd(gr, gi, u, v, pr, pi, omega, m2s2, gl_re, gl_im);
+        g_lin[row * P + c0] = gl_re;
+        g_lin[row * P + c0 + 32] = gl_im;
+      } else if (KIND == NK_WIRE2D) {
+        const float* L = lin + row * Pl + lc;
+        const float u = L[0], v = L[32], p = L[64], q = L[96];
+        const float c_r = __builtin_fmaf(pr, gr, pi * gi);
+        const float c_i = __builtin_fmaf(pr, gi, -(pi * gr));
+        const float t = m2s2 * c_r;
+        float* Gp = g_lin + row * Pl + lc;
+        Gp[0] = __builtin_fmaf(t, u, omega * c_i);
+        Gp[32] = __builtin_fmaf(t, v, -(omega * c_r));
+        Gp[64] = t * p;
+        Gp[96] = t * q;
+      } else {
+        constexpr int ACT = (KIND - NK_SIREN) < 0 ? 0 : (KIND - NK_SIREN);
+        const float l = lin[row * P + c0];
+        g_lin[row * P + c0] = real_act_bwd<ACT>(gr, l, pr, omega, scale);
+      }
+    }
+    float* pw = part_w + (size_t)blockIdx.x * O * P;
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o)
+      if (o < O) {
+        pw[(size_t)o * P + c0] = a0[o];
+        if (cplx) pw[(size_t)o * P + c0 + 32] = a1[o];
+      }
+  }
+  // bias partial: thread o < O of the first feature block sums g_y[:, o]
+  if (blockIdx.y == 0 && threadIdx.x < O) {
+    float sacc = 0.f;
+    for (int r = 0; r < nr; ++r) sacc += sgy[r * O + threadIdx.x];
+    part_b[(size_t)blockIdx.x * O + threadIdx.x] = sacc;
+  }
+}
+
+hipError_t launch_final_bwd(hipStream_t s, int kind, int raw, const float* g_y, int64_t n, int O,
+                            const float* wf, const float* lin, const float* out, int K, int P,
+                            float omega, float scale, float* g_lin, float* part_w,
+                            float* part_b) {
+  if (n <= 0) return hipSuccess;
+  if (O > MAXO) return hipErrorInvalidValue;
+  const bool cplx = (kind == NK_WIRE || kind == NK_WIRE2D);
+  const int nfeat = cplx ? P / 2 : P;
+  dim3 grid((unsigned)final_bwd_blocks(n), cdiv(nfeat, 256));
+#define FB_LAUNCH(KK, RR)                                                                        \
+  hipLaunchKernelGGL((final_bwd_kernel<KK, RR>), grid, dim3(256), 0, s, g_y, (long long)n, O, wf, \
+                     lin, out, K, P, omega, scale, g_lin, part_w, part_b)
+  if (raw) {
+    if (cplx) FB_LAUNCH(NK_WIRE, true); else FB_LAUNCH(NK_RELU, true);
+  } else {
+    switch (kind) {
+      case NK_WIRE: FB_LAUNCH(NK_WIRE, false); break;
+      case NK_WIRE2D: FB_LAUNCH(NK_WIRE2D, false); break;
+      case NK_SIREN: FB_LAUNCH(NK_SIREN, false); break;
+      case NK_GAUSS: FB_LAUNCH(NK_GAUSS, false); break;
+      case NK_RELU: FB_LAUNCH(NK_RELU, false); break;
+      default: return hipErrorInvalidValue;
+    }
+  }
+#undef FB_LAUNCH
+  return hipGetLastError();
+}
+
+// g_Wf = g_y^T conj(z):  re = sum g z_re, im = -sum g z_im;  g_bf = sum g + 0j
+__global__ void final_reduce_kernel(int kind, const float* __restrict__ part_w,
+                                    const float* __restrict__ part_b, int nblk, int O, int K, int P,
+                                    float* __restrict__ gWf, float* __restrict__ gbf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int o = blockIdx.y;
+  const bool cplx = (kind == NK_WIRE || kind == NK_WIRE2D);
+  if (i < K) {
+    if (cplx) {
+      const int c = blk_col(i, 0);
+      float sr = 0.f, si = 0.f;
+      for (int b = 0; b < nblk; ++b) {
+        const float* pw = part_w + ((size_t)b * O + o) * P;
+        sr += pw[c];
+        si += pw[c + 32];
+      }
+      gWf[((size_t)o * K + i) * 2] = sr;
+      gWf[((size_t)o * K + i) * 2 + 1] = -si;
+    } else {
+      float sr = 0.f;
+      for (int b = 0; b < nblk; ++b) sr += part_w[((size_t)b * O + o) * P + i];
+      gWf[(size_t)o * K + i] = sr;
+    }
+  }
+  if (i == 0) {
+    float sb = 0.f;
+    for (int b = 0; b < nblk; ++b) sb += part_b[(size_t)b * O + o];
+    if (cplx) { gbf[2 * o] = sb; gbf[2 * o + 1] = 0.f; } else gbf[o] = sb;
+  }
+}
+
+hipError_t launch_final_reduce(hipStream_t s, int kind, const float* part_w, const float* part_b,
+                               int nblk, int O, int K, int P, float* gWf, float* gbf) {
+  dim3 grid(cdiv(K, 64), (unsigned)O);
+  hipLaunchKernelGGL(final_reduce_kernel, grid, dim3(64), 0, s, kind, part_w, part_b, nblk, O, K, P,
+                     gWf, gbf);
+  return hipGetLastError();
+}
+
+// ===========================================================================
+// hidden weight-gradient reduction.  M = G^T Z in blocked-planar real form;
+//   g_W = g_lin^T conj(z):  re = M[(o,re),(i,re)] + M[(o,im),(i,im)]
+//                           im = M[(o,im),(i,re)] - M[(o,re),(i,im)]
+// ===========================================================================
+__global__ void wgrad_reduce_kernel(int kind, const float* __restrict__ slab,
+                                    const float* __restrict__ bslab, int S, int K, int Kin, int Pm,
+                                    int Pn, float* __restrict__ gW, float* __restrict__ gb,
+                                    float* __restrict__ gV, float* __restrict__ gc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int o = blockIdx.y;
+  const size_t sstride = (size_t)Pm * Pn;
+  if (kind == NK_WIRE || kind == NK_WIRE2D) {
+    const int nmat = (kind == NK_WIRE2D) ? 2 : 1;
+    for (int mat = 0; mat < nmat; ++mat) {
+      int r_re, r_im;
+      if (kind == NK_WIRE) {
+        r_re = blk_col(o, 0);
+        r_im = r_re + 32;
+      } else {
+        r_re = ((o >> 5) << 7) + 64 * mat + (o & 31);
+        r_im = r_re + 32;
+      }
+      float* gWm = mat == 0 ? gW : gV;
+      float* gbm = mat == 0 ? gb : gc;
+      if (i < Kin) {
+        const int c_re = blk_col(i, 0), c_im = c_re + 32;
+        float sr = 0.f, si = 0.f;
+        for (int s = 0; s < S; ++s) {
+          const float* m = slab + s * sstride;
+          sr += m[(size_t)r_re * Pn + c_re] + m[(size_t)r_im * Pn + c_im];
+          si += m[(size_t)r_im * Pn + c_re] - m[(size_t)r_re * Pn + c_im];
+        }
+        gWm[((size_t)o * Kin + i) * 2] = sr;
+        gWm[((size_t)o * Kin + i) * 2 + 1] = si;
+      }
+      if (i == 0) {
+        float br = 0.f, bi = 0.f;
+        for (int s = 0; s < S; ++s) {
+          br += bslab[(size_t)s * Pm + r_re];
+          bi += bslab[(size_t)s * Pm + r_im];
+        }
+        gbm[2 * o] = br;
+        gbm[2 * o + 1] = bi;
+      }
+    }
+  } else {
+    if (i < Kin) {
+      float sr = 0.f;
+      for (int s = 0; s < S; ++s) sr += slab[s * sstride + (size_t)o * Pn + i];
+      gW[(size_t)o * Kin + i] = sr;
+    }
+    if (i == 0) {
+      float br = 0.f;
+      for (int s = 0; s < S; ++s) br += bslab[(size_t)s * Pm + o];
+      gb[o] = br;
+    }
+  }
+}
+
+hipError_t launch_wgrad_reduce(hipStream_t s, int kind, const float* slab, const float* bslab,
+                               int S, int K, int Kin, int Pm, int Pn, float* gW, float* gb,
+                               float* gV, float* gc) {
+  dim3 grid(cdiv(Kin, 64), (unsigned)K);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, grid, dim3(64), 0, s, kind, slab, bslab, S, K, Kin, Pm,
+                     Pn, gW, gb, gV, gc);
+  return hipGetLastError();
+}
+
+// ===========================================================================
+// first-layer weight gradient: tall-skinny  G[n][C]^T [x | 1]
+// ===========================================================================
+#define CR_ROWS 512
+int colreduce_blocks(int64_t n) { return (int)((n + CR_ROWS - 1) / CR_ROWS); }
+
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ G, int ldg, int C,
+                                                        const float* __restrict__ x, int D,
+                                                        long long n, float* __restrict__ partial) {
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;
+  const long long r0 = (long long)blockIdx.x * CR_ROWS;
+  long long r1 = r0 + CR_ROWS;
+  if (r1 > n) r1 = n;
+  if (c >= C) return;
+  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long long row = r0; row < r1; ++row) {
+    const float g = G[row * ldg + c];
+    for (int d = 0; d < D; ++d) acc[d] = __builtin_fmaf(g, x[row * D + d], acc[d]);
+    acc[4] += g;
+  }
+  float* p = partial + ((size_t)blockIdx.x * C + c) * 5;
+#pragma unroll
+  for (int d = 0; d < 5; ++d) p[d] = acc[d];
+}
+
+__global__ void colreduce_final_kernel(const float* __restrict__ partial, int nblk, int C, int D,
+                                       float* __restrict__ gW0, float* __restrict__ gb0) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < nblk; ++b) {
+    const float* p = partial + ((size_t)b * C + c) * 5;
+#pragma unroll
+    for (int d = 0; d < 5; ++d) acc[d] += p[d];
+  }
+  for (int d = 0; d < D; ++d) gW0[c * D + d] = acc[d];
+  gb0[c] = acc[4];
+}
+
+hipError_t launch_colreduce(hipStream_t s, const float* G, int ldg, int C, const float* x, int D,
+                            int64_t n, float* partial, float* gW0, float* gb0) {
+  if (D > 4) return hipErrorInvalidValue;
+  const int nblk = colreduce_blocks(n);
+  dim3 grid((unsigned)nblk, cdiv(C, 256));
+  hipLaunchKernelGGL(colreduce_kernel, grid, dim3(256), 0, s, G, ldg, C, x, D, (long long)n, partial);
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, partial, nblk, C, D,
+                     gW0, gb0);
+  return hipGetLastError();
+}
+
+// ===========================================================================
+// layout conversion (per-layer API only; the fused path never leaves the
+// blocked layout)
+// ===========================================================================
+__global__ void c64_to_blocked_kernel(const float* __restrict__ src, long long n, int K, int P,
+                                      float* __restrict__ dst) {
+  const long long row = blockIdx.x;
+  for (int c = threadIdx.x; c < P; c += blockDim.x) {
+    int o, part;
+    blk_decode(c, o, part);
+    dst[row * P + c] = o < K ? src[(row * K + o) * 2 + part] : 0.f;
+  }
+}
+__global__ void blocked_to_c64_kernel(const float* __restrict__ src, long long n, int K, int P,
+                                      float* __restrict__ dst) {
+  const long long row = blockIdx.x;
+  for (int e = threadIdx.x; e < 2 * K; e += blockDim.x) {
+    const int o = e >> 1, part = e & 1;
+    dst[row * 2 * K + e] = src[row * P + blk_col(o, part)];
+  }
+}
+__global__ void pad_rows_kernel(const float* __restrict__ src, long long n, int K, int P,
+                                float* __restrict__ dst) {
+  const long long row = blockIdx.x;
+  for (int c = threadIdx.x; c < P; c += blockDim.x) dst[row * P + c] = c < K ? src[row * K + c] : 0.f;
+}
+__global__ void unpad_rows_kernel(const float* __restrict__ src, long long n, int K, int P,
+                                  float* __restrict__ dst) {
+  const long long row = blockIdx.x;
+  for (int c = threadIdx.x; c < K; c += blockDim.x) dst[row * K + c] = src[row * P + c];
+}
+
+hipError_t launch_c64_to_blocked(hipStream_t s, const float* src, int64_t n, int K, int P, float* dst) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(c64_to_blocked_kernel, dim3((unsigned)n), dim3(256), 0, s, src, (long long)n, K, P, dst);
+  return hipGetLastError();
+}
+hipError_t launch_blocked_to_c64(hipStream_t s, const float* src, int64_t n, int K, int P, float* dst) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(blocked_to_c64_kernel, dim3((unsigned)n), dim3(256), 0, s, src, (long long)n, K, P, dst);
+  return hipGetLastError();
+}
+hipError_t launch_pad_rows(hipStream_t s, const float* src, int64_t n, int K, int P, float* dst) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)n), dim3(256), 0, s, src, (long long)n, K, P, dst);
+  return hipGetLastError();
+}
+hipError_t launch_unpad_rows(hipStream_t s, const float* src, int64_t n, int K, int P, float* dst) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)n), dim3(256), 0, s, src, (long long)n, K, P, dst);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// elementwise Gabor gradient (per-layer API; the fused path does this inside
+// the data-gradient GEMM's epilogue)
+// ---------------------------------------------------------------------------
+__global__ void gabor_bwd_point_kernel(const float* __restrict__ g, const float* __restrict__ lin,
+                                       const float* __restrict__ out, long long n, int P, float omega,
+                                       float scale, float* __restrict__ g_lin) {
+  const long long row = blockIdx.x;
+  const float m2s2 = -2.f * scale * scale;
+  for (int f = threadIdx.x; f < (P >> 1); f += blockDim.x) {
+    const size_t c = (size_t)row * P + blk_col(f, 0);
+    float gl_re, gl_im;
+    gabor_bwd(g[c], g[c + 32], lin[c], lin[c + 32], out[c], out[c + 32], omega, m2s2, gl_re, gl_im);
+    g_lin[c] = gl_re;
+    g_lin[c + 32] = gl_im;
+  }
+}
+__global__ void gabor_bwd_first_point_kernel(const float* __restrict__ g, const float* __restrict__ out,
+                                             const float* __restrict__ coords, int D,
+                                             const float* __restrict__ W0, const float* __restrict__ b0,
+                                             long long n, int K, int P, float omega, float scale,
+                                             float* __restrict__ g_u, int ldu) {
+  const long long row = blockIdx.x;
+  const float m2s2 = -2.f * scale * scale;
+  for (int f = threadIdx.x; f < ldu; f += blockDim.x) {
+    float gu = 0.f;
+    if (f < K) {
+      float u = b0[f];
+      for (int d = 0; d < D; ++d) u = __builtin_fmaf(coords[row * D + d], W0[f * D + d], u);
+      const size_t c = (size_t)row * P + blk_col(f, 0);
+      gu = gabor_bwd_real(g[c], g[c + 32], u, out[c], out[c + 32], omega, m2s2);
+    }
+    g_u[row * ldu + f] = gu;
+  }
+}
+hipError_t launch_gabor_bwd_point(hipStream_t s, const float* g, const float* lin, const float* out,
+                                  int64_t n, int P, float omega, float scale, float* g_lin) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gabor_bwd_point_kernel, dim3((unsigned)n), dim3(256), 0, s, g, lin, out,
+                     (long long)n, P, omega, scale, g_lin);
+  return hipGetLastError();
+}
+hipError_t launch_gabor_bwd_first_point(hipStream_t s, const float* g, const float* out,
+                                        const float* coords, int D, const float* W0, const float* b0,
+                                        int64_t n, int K, int P, float omega, float scale, float* g_u,
+                                        int ldu) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gabor_bwd_first_point_kernel, dim3((unsigned)n), dim3(256), 0, s, g, out, coords,
+                     D, W0, b0, (long long)n, K, P, omega, scale, g_u, ldu);
+  return hipGetLastError();
+}
+
+// ===========================================================================
+// positional encoding, modules/relu.py:62-75: [c, {sin(2^i pi c_j), cos(2^i pi c_j)}_{i,j}]
+// ===========================================================================
+__global__ void posenc_kernel(const float* __restrict__ coords, long long n, int D, int F, int Pin,
+                              float* __restrict__ dst) {
+  const long long row = (long long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int c = threadIdx.x & 63;
+  for (int col = c; col < Pin; col += 64) {
+    float v = 0.f;
+    if (col < D) {
+      v = coords[row * D + col];
+    } else if (col < D + 2 * D * F) {
+      const int e = col - D;
+      const int i = e / (2 * D);
+      const int j = (e % (2 * D)) >> 1;
+      const float freq = (float)((double)(1 << i) * 3.14159265358979323846);
+      float sn, cs;
+      wire_sincos(freq * coords[row * D + j], sn, cs);
+      v = (e & 1) ? cs : sn;
+    }
+    dst[row * Pin + col] = v;
+  }
+}
+hipError_t launch_posenc(hipStream_t s, const float* coords, int64_t n, int D, int F, int Pin,
+                         float* dst) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(posenc_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, coords, (long long)n, D, F,
+                     Pin, dst);
+  return hipGetLastError();
+}
+
+// ===========================================================================
+// training glue
+// ===========================================================================
+__global__ void coords_kernel(const int64_t* __restrict__ idx, long long first, long long n,
+                              const float* __restrict__ tx, int W, const float* __restrict__ ty,
+                              int H, const float* __restrict__ tz, int T,
+                              float* __restrict__ coords) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  long long id = idx ? idx[r] : first + r;
+  if (tz) {
+    const long long k = id % T;
+    id /= T;
+    const long long j = id % W, i = id / W;
+    coords[r * 3 + 0] = tx[j];
+    coords[r * 3 + 1] = ty[i];
+    coords[r * 3 + 2] = tz[k];
+  } else {
+    const long long j = id % W, i = id / W;
+    coords[r * 2 + 0] = tx[j];
+    coords[r * 2 + 1] = ty[i];
+  }
+}
+hipError_t launch_coords(hipStream_t s, const int64_t* idx, int64_t first, int64_t n,
+                         const float* tx, int W, const float* ty, int H, const float* tz, int T,
+                         float* coords) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(coords_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, idx, (long long)first,
+                     (long long)n, tx, W, ty, H, tz, T, coords);
+  return hipGetLastError();
+}
+
+#define MSE_BLOCKS 1024
+__global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ y,
+                                                       const float* __restrict__ target,
+                                                       const int64_t* __restrict__ idx,
+                                                       long long first, long long n, int O,
+                                                       float gscale, float* __restrict__ g_y,
+                                                       float* __restrict__ rec,
+                                                       float* __restrict__ partial) {
+  __shared__ float red[256];
+  const long long total = n * O;
+  float acc = 0.f;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long r = e / O;
+    const int o = (int)(e - r * O);
+    const long long src = idx ? idx[r] : first + r;
+    const float yy = y[e];
+    const float d = yy - target[src * O + o];
+    g_y[e] = gscale * d;
+    if (rec) rec[src * O + o] = yy;
+    acc = __builtin_fmaf(d, d, acc);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int sft = 128; sft >= 1; sft >>= 1) {
+    if (threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void mse_final_kernel(const float* __restrict__ partial, int nb, float lscale,
+                                 float* __restrict__ loss_out) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) acc += partial[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int sft = 128; sft >= 1; sft >>= 1) {
+    if (threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_out[0] = red[0] * lscale;
+}
+hipError_t launch_mse_grad(hipStream_t s, const float* y, const float* target, const int64_t* idx,
+                           int64_t first, int64_t n, int O, float weight, float* g_y,
+                           float* loss_out, float* rec, float* partial) {
+  if (n <= 0) return hipSuccess;
+  unsigned nb = cdiv(n * O, 256);
+  if (nb > MSE_BLOCKS) nb = MSE_BLOCKS;
+  const float inv = (float)(1.0 / ((double)n * (double)O));
+  hipLaunchKernelGGL(mse_grad_kernel, dim3(nb), dim3(256), 0, s, y, target, idx, (long long)first,
+                     (long long)n, O, weight * 2.f * inv, g_y, rec, partial);
+  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, s, partial, (int)nb, weight * inv,
+                     loss_out);
+  return hipGetLastError();
+}
+
+// torch.optim.Adam (_single_tensor_adam): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) m/denom
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v, long long count,
+                            float step_size, float beta1, float beta2, float eps,
+                            float inv_sqrt_bc2) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float gg = g[i];
+  const float mm = __builtin_fmaf(beta1, m[i], (1.f - beta1) * gg);
+  const float vv = __builtin_fmaf(beta2, v[i], (1.f - beta2) * gg * gg);
+  m[i] = mm;
+  v[i] = vv;
+  const float denom = __builtin_fmaf(__builtin_sqrtf(vv), inv_sqrt_bc2, eps);
+  p[i] = p[i] - step_size * (mm / denom);
+}
+hipError_t launch_adam(hipStream_t s, float* p, const float* g, float* m, float* v, int64_t count,
+                       float step_size, float beta1, float beta2, float eps, float inv_sqrt_bc2) {
+  if (count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(adam_kernel, dim3(cdiv(count, 256)), dim3(256), 0, s, p, g, m, v,
+                     (long long)count, step_size, beta1, beta2, eps, inv_sqrt_bc2);
+  return hipGetLastError();
+}
