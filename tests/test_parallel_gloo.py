@@ -1,0 +1,68 @@
+"""world_size-2 (gloo, CPU) test of the data-parallel exchange: each rank
+computes the gradient of ITS shard's loss (scaled by n_g/B) with the oracle,
+FlatGradAllReducer sums the flat buffers, and the result must equal the
+full-batch gradient -- including an odd batch (unequal shards) and bucketed
+launches.  The compute here is the oracle; the exchange logic under test is the
+product's (wire_amd/parallel.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from _util import ROOT, load_golden, meta
+
+
+def _flat(grads, order):
+    from oracle import wire_oracle as wo
+    return np.concatenate([wo.as_real_pairs(grads[k]).astype(np.float64).ravel() for k in order])
+
+
+def _worker(rank, world, port, B, bucket, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import wire_oracle as wo
+    from wire_amd.parallel import FlatGradAllReducer, shard_bounds, shard_weight
+    rec = load_golden("small_wire_d2")
+    m = meta(rec)
+    P = wo.cast_params({k[2:]: v for k, v in rec.items() if k.startswith("p:") and "omega" not in k
+                        and "scale_0" not in k}, True)
+    order = list(P.keys())
+    coords = rec["coords"][0, :B].astype(np.float64)
+    target = rec["target"][0, :B].astype(np.float64)
+    lo, hi = shard_bounds(B, world, rank)
+    w = shard_weight(B, world, rank)
+    y, cache = wo.wire_forward(P, coords[lo:hi], m["L"], m["om1"], m["om"], m["sc"], keep=True)
+    loss, gy = wo.mse_loss_and_grad(y, target[lo:hi])
+    g = wo.wire_backward(P, cache, gy * w, m["L"], m["om1"], m["om"], m["sc"])
+    flat = torch.tensor(np.concatenate([_flat(g, order), [loss * w]]))
+    red = FlatGradAllReducer(flat, bucket_floats=bucket)
+    assert red.active and len(red.buckets) == (1 if not bucket else -(-flat.numel() // bucket))
+    red()
+    if rank == 0:
+        np.save(os.path.join(out_dir, "reduced.npy"), flat.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B,bucket", [(256, None), (257, 1000)])
+def test_sharded_gradient_equals_full_batch(tmp_path, B, bucket):
+    from oracle import wire_oracle as wo
+    port = 29500 + (os.getpid() % 2000) + (1 if bucket else 0)
+    mp.spawn(_worker, args=(2, port, B, bucket, str(tmp_path)), nprocs=2, join=True)
+    red = np.load(tmp_path / "reduced.npy")
+    rec = load_golden("small_wire_d2")
+    m = meta(rec)
+    P = wo.cast_params({k[2:]: v for k, v in rec.items() if k.startswith("p:") and "omega" not in k
+                        and "scale_0" not in k}, True)
+    y, cache = wo.wire_forward(P, rec["coords"][0, :B].astype(np.float64), m["L"], m["om1"], m["om"], m["sc"], keep=True)
+    loss, gy = wo.mse_loss_and_grad(y, rec["target"][0, :B].astype(np.float64))
+    g = wo.wire_backward(P, cache, gy, m["L"], m["om1"], m["om"], m["sc"])
+    full = np.concatenate([_flat(g, list(P.keys())), [loss]])
+    assert np.abs(red - full).max() <= 1e-12 * np.abs(full).max()

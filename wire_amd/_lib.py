@@ -10,6 +10,10 @@ import ctypes as C
 import os
 from typing import Optional
 
+# torch must load ITS HIP runtime (torch/lib/libamdhip64.so) before this library
+# pulls one in by SONAME: two runtimes in one process see no device.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwire_hip.so")
 

@@ -60,13 +60,13 @@ struct ProfScope {
     if (!g_prof_pool.empty()) {
       a = g_prof_pool.back().first; b = g_prof_pool.back().second; g_prof_pool.pop_back();
     } else {
-      hipEventCreate(&a); hipEventCreate(&b);
+      (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     }
-    hipEventRecord(a, s);
+    (void)hipEventRecord(a, s);
   }
   ~ProfScope() {
     if (!on) return;
-    hipEventRecord(b, s);
+    (void)hipEventRecord(b, s);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_recs.push_back({a, b, cls, flops});
   }

@@ -34,12 +34,17 @@ struct GemmEpiParams {
   const float* b0b = nullptr;
   int D = 0;
   int ldu = 0;
+#ifdef WIRE_ABLATE
+  int ablate = 0;                // tools/gemm_tune only: 1 no global loads, 2 no LDS writes, 4 no barrier
+#endif
 };
 
 // C = A * Bt^T with fused epilogue.  A [M][lda], Bt [Nc][ldb]; Nc % 64 == 0,
 // Kd % 32 == 0, lda/ldb % 4 == 0.
 hipError_t launch_gemm_nt(hipStream_t s, int epi, const float* A, int lda, const float* Bt,
                           int ldb, int64_t M, int Nc, int Kd, const GemmEpiParams& ep);
+
+int gemm_tune_set(const char* key, int value);
 
 // Split-over-rows TN GEMM  slab[s][Pm][Pn] = G[rows_s][Pm]^T * Z[rows_s][Pn]
 // (+ optional column sums of G into bslab[s][Pm]).  Returns the number of

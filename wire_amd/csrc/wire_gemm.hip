@@ -20,13 +20,17 @@
 // wave a 64x64 (or 32x128) block of v_mfma_f32_32x32x2_f32 tiles, BK = 32,
 // double-buffered LDS, two workgroups per CU so one workgroup's epilogue
 // (VALU transcendental work) overlaps the other's MFMA stream.
+#include <cstdlib>
+#include <cstring>
+
 #include "wire_dev.h"
 #include "wire_gemm.h"
 
 #define BM 128
 #define BN 128
-#define BK 32
-#define LDS_STRIDE 36   // floats per LDS row: 32 + 4 pad -> conflict-free ds_read_b128
+// BKT (K-slab per LDS stage) is a template parameter: 32 -> 72 KB LDS, 2 workgroups/CU;
+// 16 -> 40 KB LDS, 3 workgroups/CU.  LDS rows are padded by 4 floats (strides 36 / 20):
+// both make the 16-lane groups of ds_read_b128 hit 16 distinct 4-bank slots.
 
 // ---------------------------------------------------------------------------
 // epilogue bodies: one complex feature (re, im accumulators of the same lane)
@@ -38,10 +42,15 @@ struct EpiTraits {
   static constexpr bool quad = (EPI == EPI_GABOR2D_FWD);
 };
 
-template <int EPI, int MT, int WN>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
+template <int EPI, int MT, int WN, int BKT>
+__global__ __launch_bounds__(256, (BKT == 32 ? 2 : 3)) void gemm_nt_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ Bt, int ldb, int M, int Nc,
     int Kd, int tiles_m, int tiles_n, GemmEpiParams ep) {
+  constexpr int LDS_STRIDE = BKT + 4;
+  constexpr int BK = BKT;
+  constexpr int TPR = BKT / 4;          // loader threads per tile row
+  constexpr int RPP = 256 / TPR;        // tile rows per loader pass
+  constexpr int NP = BM / RPP;          // loader passes per operand
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * LDS_STRIDE];
 
   const int tid = threadIdx.x;
@@ -64,16 +73,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   const int m_base = rt * BM;
   const int n_base = ct * BN;
 
-  // ---- global -> register staging map: 8 threads x float4 per 32-float row
-  const int lrow = tid >> 3;
-  const int lc4 = (tid & 7) * 4;
-  const float* a_src[4];
-  const float* b_src[4];
+  // ---- global -> register staging map: TPR threads x float4 per BK-float row
+  const int lrow = tid / TPR;
+  const int lc4 = (tid % TPR) * 4;
+  const float* a_src[NP];
+  const float* b_src[NP];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    int ra = m_base + lrow + 32 * p;
+  for (int p = 0; p < NP; ++p) {
+    int ra = m_base + lrow + RPP * p;
     ra = ra < M ? ra : M - 1;
-    int rb = n_base + lrow + 32 * p;
+    int rb = n_base + lrow + RPP * p;
     rb = rb < Nc ? rb : Nc - 1;
     a_src[p] = A + (size_t)ra * lda + lc4;
     b_src[p] = Bt + (size_t)rb * ldb + lc4;
@@ -91,9 +100,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   const bool wave_live = (n_base + wave_n * (WN * 32)) < Nc;
   const int nk = Kd / BK;
 
-  f32x4 ra4[4], rb4[4];
+#ifdef WIRE_ABLATE
+  if (ep.ablate & 8) {
+    // distinct static priority per wave slot of the SIMD -> co-resident workgroups drift apart
+    const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11));  // HW_ID[3:0] wave_id
+    switch (hwid & 3) {
+      case 0: __builtin_amdgcn_s_setprio(0); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      default: __builtin_amdgcn_s_setprio(3); break;
+    }
+  }
+#endif
+
+  f32x4 ra4[NP], rb4[NP];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < NP; ++p) {
     ra4[p] = *reinterpret_cast<const f32x4*>(a_src[p]);
     rb4[p] = *reinterpret_cast<const f32x4*>(b_src[p]);
   }
@@ -101,9 +123,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     float* As = smem;
     float* Bs = smem + BM * LDS_STRIDE;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      *reinterpret_cast<f32x4*>(&As[st_off + 32 * p * LDS_STRIDE]) = ra4[p];
-      *reinterpret_cast<f32x4*>(&Bs[st_off + 32 * p * LDS_STRIDE]) = rb4[p];
+    for (int p = 0; p < NP; ++p) {
+      *reinterpret_cast<f32x4*>(&As[st_off + RPP * p * LDS_STRIDE]) = ra4[p];
+      *reinterpret_cast<f32x4*>(&Bs[st_off + RPP * p * LDS_STRIDE]) = rb4[p];
     }
   }
   __syncthreads();
@@ -114,9 +136,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     const bool more = (kt + 1) < nk;
+#ifdef WIRE_ABLATE
+    if (more && !(ep.ablate & 1)) {
+#else
     if (more) {
+#endif
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
+      for (int p = 0; p < NP; ++p) {
         ra4[p] = *reinterpret_cast<const f32x4*>(a_src[p] + (kt + 1) * BK);
         rb4[p] = *reinterpret_cast<const f32x4*>(b_src[p] + (kt + 1) * BK);
       }
@@ -125,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     const float* Bs = As + BM * LDS_STRIDE;
     if (wave_live) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < BK / 8; ++q) {
         f32x4 af[MT], bf[WN];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -142,15 +168,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
       }
     }
+#ifdef WIRE_ABLATE
+    if (more && !(ep.ablate & 2)) {
+#else
     if (more) {
+#endif
       float* Aw = smem + (buf ^ 1) * (2 * BM * LDS_STRIDE);
       float* Bw = Aw + BM * LDS_STRIDE;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        *reinterpret_cast<f32x4*>(&Aw[st_off + 32 * p * LDS_STRIDE]) = ra4[p];
-        *reinterpret_cast<f32x4*>(&Bw[st_off + 32 * p * LDS_STRIDE]) = rb4[p];
+      for (int p = 0; p < NP; ++p) {
+        *reinterpret_cast<f32x4*>(&Aw[st_off + RPP * p * LDS_STRIDE]) = ra4[p];
+        *reinterpret_cast<f32x4*>(&Bw[st_off + RPP * p * LDS_STRIDE]) = rb4[p];
       }
     }
+#ifdef WIRE_ABLATE
+    if (!(ep.ablate & 4))
+#endif
     __syncthreads();
   }
   if (!wave_live) return;
@@ -378,6 +411,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   }
 }
 
+// tuning knobs (wire_tune_set; defaults may be overridden by WIRE_NT_BK in the environment)
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+static int g_nt_bk = env_int("WIRE_NT_BK", 16);   // K-slab depth of the NT kernel: 16 or 32
+static int nt_bk() { return g_nt_bk; }
+int gemm_tune_set(const char* key, int value) {
+  if (!strcmp(key, "nt_bk") && (value == 16 || value == 32)) { g_nt_bk = value; return 0; }
+  return -1;
+}
+
 template <int EPI, int MT, int WN>
 static hipError_t launch_nt_t(hipStream_t s, const float* A, int lda, const float* Bt, int ldb,
                               int64_t M, int Nc, int Kd, const GemmEpiParams& ep) {
@@ -385,8 +430,12 @@ static hipError_t launch_nt_t(hipStream_t s, const float* A, int lda, const floa
   const int tiles_n = (Nc + BN - 1) / BN;
   const int tiles_m_pad = (tiles_m + 7) & ~7;
   dim3 grid((unsigned)(tiles_m_pad * tiles_n));
-  hipLaunchKernelGGL((gemm_nt_kernel<EPI, MT, WN>), grid, dim3(256), 0, s, A, lda, Bt, ldb, (int)M,
-                     Nc, Kd, tiles_m, tiles_n, ep);
+  if (nt_bk() == 16)
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, MT, WN, 16>), grid, dim3(256), 0, s, A, lda, Bt, ldb,
+                       (int)M, Nc, Kd, tiles_m, tiles_n, ep);
+  else
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, MT, WN, 32>), grid, dim3(256), 0, s, A, lda, Bt, ldb,
+                       (int)M, Nc, Kd, tiles_m, tiles_n, ep);
   return hipGetLastError();
 }
 
@@ -422,16 +471,22 @@ hipError_t launch_gemm_nt(hipStream_t s, int epi, const float* A, int lda, const
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(
     const float* __restrict__ G, int ldg, const float* __restrict__ Z, int ldz, long long n,
-    int Pm, int Pn, int tiles_n, long long chunk, float* __restrict__ slab,
-    float* __restrict__ bslab) {
+    int Pm, int Pn, int tiles_n, int nsplit, long long chunk, float* __restrict__ slab,
+    float* __restrict__ bslab, int tiles) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TK * 128];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wave_m = wave >> 1, wave_n = wave & 1;
   const int l31 = lane & 31, h = lane >> 5;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
-  const int split = blockIdx.y;
+  // XCD-aware order: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch), and the
+  // `tiles` output tiles of one row split all read the same G/Z rows -> keep them on one L2.
+  const int bb = blockIdx.x;
+  const int xcd = bb & 7, idx = bb >> 3;
+  const int tile = idx % tiles;
+  const int split = (idx / tiles) * 8 + xcd;
+  if (split >= nsplit) return;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int m_base = tm * 128, n_base = tn * 128;
   const long long row0 = (long long)split * chunk;
   long long row1 = row0 + chunk;
@@ -564,8 +619,9 @@ hipError_t launch_gemm_tn(hipStream_t s, const float* G, int ldg, const float* Z
   long long chunk = (n + splits - 1) / splits;
   chunk = (chunk + TK - 1) / TK * TK;
   if (chunk < TK) chunk = TK;
-  dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splits);
+  const int splits_pad = (splits + 7) & ~7;
+  dim3 grid((unsigned)(tiles_m * tiles_n * splits_pad), 1);
   hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, s, G, ldg, Z, ldz, (long long)n, Pm, Pn,
-                     tiles_n, chunk, slab, bslab);
+                     tiles_n, splits, chunk, slab, bslab, tiles_m * tiles_n);
   return hipGetLastError();
 }

@@ -1,0 +1,212 @@
+"""Sync-free fused training step for the image-fit / occupancy loops.
+
+Restates the inner loop of the reference's drivers
+(wire_image_denoise.py:142-157, wire_occupancy.py:137-158):
+
+    b_coords = coords[b_indices]; pix = model(b_coords); rec[b_indices] = pix
+    loss = ((pix - gt[b_indices])**2).mean(); zero_grad; backward; Adam.step
+
+as a fixed sequence of libwire_hip launches on one HIP stream with no host
+synchronisation: coordinates are generated on the device from the flat indices
+(per-axis linspace tables, bit-identical to the reference's grids), the MSE
+gradient, the whole backward and a flat Adam update (complex parameters as real
+pairs, exactly torch.optim.Adam's arithmetic) are HIP kernels.  The host gather
++ H2D copy and the per-step ``loss.item()`` of the reference are gone.
+
+Multi-GPU: one process per GPU; the global batch is sharded contiguously
+(parallel.shard_bounds), each shard's gradient is pre-scaled by n_g/B and one
+RCCL all-reduce (SUM) of the flat gradient buffer runs on a side stream.  With
+``micro_shards > 1`` the all-reduce of micro-shard i overlaps the forward and
+backward of micro-shard i+1.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .modules._base import HipINR
+from .modules.utils import axis_tables
+from .parallel import FlatGradAllReducer, shard_bounds
+
+
+class FusedTrainer:
+    def __init__(self, model: HipINR, grid: Sequence[int], target: torch.Tensor, lr: float = 5e-3,
+                 betas=(0.9, 0.999), eps: float = 1e-8, gamma: float = 0.1, niters: int = 2000,
+                 coords_style: str = "torch", keep_rec: bool = False, micro_shards: int = 1,
+                 group: Optional[dist.ProcessGroup] = None):
+        self.L = _lib.lib()
+        p0 = next(model.parameters())
+        if not p0.is_cuda:
+            raise _lib.WireHipError("FusedTrainer needs the model on an MI355X ('cuda')")
+        self.model = model
+        self.dev = p0.device
+        self.desc = model.net_desc()
+        self.grid = tuple(int(g) for g in grid)
+        if len(self.grid) not in (2, 3) or len(self.grid) != self.desc.in_features:
+            raise ValueError("grid must be (H, W) for 2 inputs or (H, W, T) for 3")
+        H, W = self.grid[0], self.grid[1]
+        T = self.grid[2] if len(self.grid) == 3 else None
+        tx, ty, tz = axis_tables(H, W, T, style=coords_style)
+        self.tx, self.ty = tx.to(self.dev), ty.to(self.dev)
+        self.tz = tz.to(self.dev) if tz is not None else None
+        self.npoints = H * W * (T or 1)
+        self.O = self.desc.out_features
+        self.target = target.to(self.dev, torch.float32).reshape(self.npoints, self.O).contiguous()
+        self.rec = torch.zeros_like(self.target) if keep_rec else None
+
+        # ---- flat parameter / gradient / Adam-state buffers; parameters become views
+        tensors = model.param_tensors()
+        self.sizes = [int(_lib.check(self.L.wire_param_tensor_floats(C.byref(self.desc), i)))
+                      for i in range(len(tensors))]
+        # every tensor starts on a 16-byte boundary (complex views need an even
+        # float offset); the pad floats stay zero in params, grads and Adam state
+        padded = [(sz + 3) // 4 * 4 for sz in self.sizes]
+        self.count = sum(padded)
+        self.flat = torch.zeros(self.count, dtype=torch.float32, device=self.dev)
+        off = 0
+        self.offsets: List[int] = []
+        with torch.no_grad():
+            for t, sz in zip(tensors, self.sizes):
+                src = torch.view_as_real(t.detach()).reshape(-1) if t.is_complex() else t.detach().reshape(-1)
+                if src.numel() != sz:
+                    raise _lib.WireHipError("parameter size does not match the ABI's layout")
+                view = self.flat[off:off + sz]
+                view.copy_(src)
+                t.data = torch.view_as_complex(view.view(*t.shape, 2)) if t.is_complex() \
+                    else view.view(t.shape)
+                self.offsets.append(off)
+                off += (sz + 3) // 4 * 4
+        self.micro = max(1, int(micro_shards))
+        # +1: the loss rides at the end of each gradient buffer through the all-reduce
+        self.gbuf = [torch.zeros(self.count + 1, dtype=torch.float32, device=self.dev)
+                     for _ in range(self.micro)]
+        self.exp_avg = torch.zeros(self.count, dtype=torch.float32, device=self.dev)
+        self.exp_avg_sq = torch.zeros(self.count, dtype=torch.float32, device=self.dev)
+        fp = self.flat.data_ptr()
+        self.param_ptrs = _lib.ptr_array([fp + 4 * o for o in self.offsets])
+        self.grad_ptrs = [_lib.ptr_array([g.data_ptr() + 4 * o for o in self.offsets]) for g in self.gbuf]
+        self.packed = torch.empty(self.L.wire_packed_floats(C.byref(self.desc)), dtype=torch.float32,
+                                  device=self.dev)
+        self.partial = torch.empty(4096, dtype=torch.float32, device=self.dev)
+
+        self.base_lr, self.betas, self.eps = float(lr), betas, float(eps)
+        self.gamma, self.niters = float(gamma), int(niters)
+        self.epoch = 0
+        self.t = 0
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.reducers = [FlatGradAllReducer(g, group) for g in self.gbuf]
+        self._cap = 0
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
+
+    # ------------------------------------------------------------------ buffers
+    def _reserve(self, n: int) -> None:
+        if n <= self._cap:
+            return
+        d = C.byref(self.desc)
+        self.act_bytes = _lib.check(self.L.wire_act_bytes(d, n, 1))
+        self.scr_bytes = _lib.check(self.L.wire_bwd_scratch_bytes(d, n))
+        self.act = torch.empty(self.act_bytes, dtype=torch.uint8, device=self.dev)
+        self.scratch = torch.empty(self.scr_bytes, dtype=torch.uint8, device=self.dev)
+        self.coords = torch.empty(n * self.desc.in_features, dtype=torch.float32, device=self.dev)
+        self.y = torch.empty(n * self.O, dtype=torch.float32, device=self.dev)
+        self.gy = torch.empty(n * self.O, dtype=torch.float32, device=self.dev)
+        self._cap = n
+
+    # ------------------------------------------------------------------ schedule
+    def current_lr(self) -> float:
+        """LambdaLR(lambda x: gamma**min(x/niters, 1)) (wire_image_denoise.py:128)."""
+        return self.base_lr * self.gamma ** min(self.epoch / self.niters, 1)
+
+    def scheduler_step(self) -> None:
+        self.epoch += 1
+
+    # ------------------------------------------------------------------ one step
+    def step(self, indices: Optional[torch.Tensor] = None, first: int = 0,
+             count: Optional[int] = None) -> torch.Tensor:
+        """One optimizer step on a global batch: rows ``indices`` (int64 device
+        tensor of flat grid indices) or the range [first, first+count).
+        Returns the (device-resident, all-reduced) batch loss; no host sync."""
+        L, d = self.L, C.byref(self.desc)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        if indices is not None:
+            if indices.dtype != torch.int64 or not indices.is_cuda:
+                raise ValueError("indices must be a CUDA int64 tensor")
+            B = indices.numel()
+        else:
+            B = int(count if count is not None else self.npoints - first)
+        lo, hi = shard_bounds(B, self.world, self.rank)
+        _lib.check(L.wire_pack_params(stream, d, self.param_ptrs, self.packed.data_ptr()), "pack")
+        nloc = hi - lo
+        per = (nloc + self.micro - 1) // self.micro
+        self._reserve(max(per, 1))
+        tz_ptr = self.tz.data_ptr() if self.tz is not None else None
+        Tn = self.grid[2] if self.tz is not None else 1
+        for m in range(self.micro):
+            mlo = lo + m * per
+            n = max(0, min(hi, mlo + per) - mlo)
+            g = self.gbuf[m]
+            if n == 0:
+                g.zero_()
+            else:
+                idx_ptr = (indices.data_ptr() + 8 * mlo) if indices is not None else None
+                _lib.check(L.wire_coords_from_index(stream, idx_ptr, first + mlo, n, self.tx.data_ptr(),
+                                                    self.grid[1], self.ty.data_ptr(), self.grid[0],
+                                                    tz_ptr, Tn, self.coords.data_ptr()), "coords")
+                _lib.check(L.wire_mlp_fwd(stream, d, self.packed.data_ptr(), self.coords.data_ptr(), n,
+                                          self.y.data_ptr(), self.act.data_ptr(), self.act_bytes, 1), "fwd")
+                _lib.check(L.wire_mse_grad(stream, self.y.data_ptr(), self.target.data_ptr(), idx_ptr,
+                                           first + mlo, n, self.O, n / float(B), self.gy.data_ptr(),
+                                           g.data_ptr() + 4 * self.count,
+                                           self.rec.data_ptr() if self.rec is not None else None,
+                                           self.partial.data_ptr()), "mse")
+                _lib.check(L.wire_mlp_bwd(stream, d, self.packed.data_ptr(), self.coords.data_ptr(), n,
+                                          self.gy.data_ptr(), self.act.data_ptr(), self.act_bytes,
+                                          self.scratch.data_ptr(), self.scr_bytes, self.grad_ptrs[m]), "bwd")
+            self.reducers[m].launch()
+        for r in self.reducers:
+            r.wait()
+        gsum = self.gbuf[0]
+        for m in range(1, self.micro):
+            gsum.add_(self.gbuf[m])
+        self.t += 1
+        _lib.check(L.wire_adam_step_flat(stream, self.flat.data_ptr(), gsum.data_ptr(),
+                                         self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.count,
+                                         self.current_lr(), self.betas[0], self.betas[1], self.eps,
+                                         self.t), "adam")
+        self.loss = gsum[self.count:self.count + 1].clone()   # the buffer is reused next step
+        return self.loss
+
+    @property
+    def flat_grad(self) -> torch.Tensor:
+        return self.gbuf[0][:self.count]
+
+    # ------------------------------------------------------------------ inference
+    @torch.no_grad()
+    def render(self, first: int = 0, count: Optional[int] = None, tile: int = 1 << 20) -> torch.Tensor:
+        """Forward-only dense query of grid rows [first, first+count) in tiles
+        (no saved activations): the reference's full-image / volume evaluation."""
+        L, d = self.L, C.byref(self.desc)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        count = int(count if count is not None else self.npoints - first)
+        out = torch.empty(count, self.O, dtype=torch.float32, device=self.dev)
+        _lib.check(L.wire_pack_params(stream, d, self.param_ptrs, self.packed.data_ptr()), "pack")
+        tile = min(tile, max(count, 1))
+        ab = _lib.check(L.wire_act_bytes(d, tile, 0))
+        act = torch.empty(ab, dtype=torch.uint8, device=self.dev)
+        coords = torch.empty(tile * self.desc.in_features, dtype=torch.float32, device=self.dev)
+        tz_ptr = self.tz.data_ptr() if self.tz is not None else None
+        Tn = self.grid[2] if self.tz is not None else 1
+        for s in range(0, count, tile):
+            n = min(tile, count - s)
+            _lib.check(L.wire_coords_from_index(stream, None, first + s, n, self.tx.data_ptr(), self.grid[1],
+                                                self.ty.data_ptr(), self.grid[0], tz_ptr, Tn,
+                                                coords.data_ptr()), "coords")
+            _lib.check(L.wire_mlp_fwd(stream, d, self.packed.data_ptr(), coords.data_ptr(), n,
+                                      out.data_ptr() + 4 * s * self.O, act.data_ptr(), ab, 0), "fwd")
+        return out
