@@ -165,6 +165,14 @@ int wire_blocked_width(int K);   /* P = roundup(2K, 64) */
 int wire_c64_to_blocked(void* stream, const void* src, int64_t n, int K, float* dst);
 int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* dst);
 
+/* ---- tuning knobs ---------------------------------------------------------
+ * "complex_3m" (default 1): wire layers use the 3-multiplication complex GEMMs
+ *     (6 real flop per complex MAC on the matrix cores); 0 = 4-multiplication
+ *     real-expanded GEMMs.  Packed images differ: re-run wire_pack_params (and
+ *     re-query the size functions) after changing it.
+ * "nt_bk" (16 | 32): K-slab depth of the 4-multiplication NT kernel.          */
+int wire_tune_set(const char* key, int value);
+
 /* ---- profiling hooks (bench.py roofline) -------------------------------
  * When enabled, every launch of the hot kernels is bracketed by hipEvents on
  * the launch stream; wire_prof_read synchronises those events and returns

@@ -70,11 +70,38 @@ def test_full_configs(name):
     _, _, g64, _ = oracle_run(rec, P, double=True)
     _, _, g32, _ = oracle_run(rec, P, double=False)
     for k, g in grads.items():
-        ref_err = relmax(g32[k], g64[k])
+        # a gradient inherits the forward pass's round-off (err_ref) on top of its own
+        ref_err = relmax(g32[k], g64[k]) + 0.05 * err_ref
         assert relmax(g, g64[k]) <= 4 * ref_err + 3e-6, k
         head = g[:8, :8] if g.ndim == 2 else g[:16]
         scale = float(rec["g64norm:" + k])
         assert np.abs(head - rec["g64head:" + k]).max() <= (4 * ref_err + 3e-6) * scale, k
+
+
+def test_complex_3m_vs_4m_accuracy():
+    """The 3-multiplication complex GEMM (default) and the 4-multiplication one both
+    meet the parity bar, and 3M is not materially less accurate (normwise-stable;
+    its extra cancellation shows up as a small constant factor)."""
+    from wire_amd import _lib
+    L = _lib.lib()
+    errs = {}
+    try:
+        for mode in (0, 1):
+            _lib.check(L.wire_tune_set(b"complex_3m", mode))
+            for name in ("small_wire_hi", "full_cfg2_wire_4x363_lit"):
+                rec = load_golden(name)
+                model = load_small(rec, build_model(rec)) if name.startswith("small") else build_model(rec).to(DEV)
+                y, loss, grads = hip_forward_backward(model, rec)
+                err_ref = relmax(rec["y"], rec["y64"])
+                e = relmax(y, rec["y64"])
+                assert e <= 4 * err_ref + 3e-6, (mode, name)
+                errs[(mode, name)] = (e, err_ref)
+    finally:
+        _lib.check(L.wire_tune_set(b"complex_3m", 1))
+    for name in ("small_wire_hi", "full_cfg2_wire_4x363_lit"):
+        e4, e3 = errs[(0, name)][0], errs[(1, name)][0]
+        print(f"{name}: err 4M {e4:.3e}  3M {e3:.3e}  reference fp32 {errs[(0, name)][1]:.3e}")
+        assert e3 <= 3 * e4 + 1e-6
 
 
 @pytest.mark.parametrize("name", ["small_wire_d2", "small_wire_d3", "small_wire_hi"])

@@ -93,6 +93,17 @@ extern "C" int wire_prof_read(double* ms_total, int64_t* launches, double* flops
 }
 
 // ---------------------------------------------------------------------------
+// tuning knobs
+// ---------------------------------------------------------------------------
+static int g_complex_3m = 1;   // wire: 3-multiplication complex GEMMs (wire_gemm3m.hip)
+extern "C" int wire_tune_set(const char* key, int value) {
+  if (!key) return fail(WIRE_ERR_ARG, "null key");
+  if (!strcmp(key, "complex_3m")) { g_complex_3m = value ? 1 : 0; return WIRE_OK; }
+  if (gemm_tune_set(key, value) == 0) return WIRE_OK;
+  return fail(WIRE_ERR_ARG, "unknown tuning key or bad value: %s=%d", key, value);
+}
+
+// ---------------------------------------------------------------------------
 // network plan
 // ---------------------------------------------------------------------------
 namespace {
@@ -101,8 +112,8 @@ inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 struct Plan {
   int kind, D, K, L, O, F;
   float w1, w, s;
-  bool cplx, first_gemm;
-  int P, Pl, Din, Pin0, ldu, ntens, per_layer;
+  bool cplx, first_gemm, m3;
+  int P, Pl, Din, Pin0, ldu, ntens, per_layer, Kp;
   // packed image offsets (floats); index l = 0..L (l = 0 only when first_gemm)
   std::vector<int64_t> off_fwd, off_dg, off_bias;
   int64_t off_wf, off_bf, off_first, total_packed;
@@ -124,6 +135,8 @@ int make_plan(const wire_net_desc* d, Plan& p) {
   p.P = p.cplx ? rup(2 * p.K, 64) : rup(p.K, 64);
   p.Pl = (p.kind == WIRE_KIND_WIRE2D) ? 2 * p.P : p.P;
   p.ldu = p.P / 2;
+  p.Kp = p.P / 2;
+  p.m3 = (p.kind == WIRE_KIND_WIRE) && g_complex_3m;
   p.first_gemm = p.F > 0;
   p.Din = p.first_gemm ? p.D + 2 * p.D * p.F : p.D;
   p.Pin0 = p.first_gemm ? rup(p.Din, 64) : 0;
@@ -146,8 +159,9 @@ int make_plan(const wire_net_desc* d, Plan& p) {
   p.off_fwd.assign(p.L + 1, -1); p.off_dg.assign(p.L + 1, -1); p.off_bias.assign(p.L + 1, -1);
   for (int l = p.first_gemm ? 0 : 1; l <= p.L; ++l) {
     const int64_t pin = (l == 0) ? p.Pin0 : p.P;
-    p.off_fwd[l] = off; off += (int64_t)p.Pl * pin;
-    p.off_dg[l] = off; off += (int64_t)p.Pl * pin;
+    const int64_t img = p.m3 ? (int64_t)p.Kp * p.P : (int64_t)p.Pl * pin;   // 3M keeps W itself (2 planes)
+    p.off_fwd[l] = off; off += img;
+    p.off_dg[l] = off; off += img;
     p.off_bias[l] = off; off += p.Pl;
   }
   p.off_wf = off; off += (int64_t)p.O * p.P;
@@ -192,10 +206,16 @@ ScratchLayout scratch_layout(const Plan& p, int64_t n) {
   s.ga = off; off += n * p.Pl;
   s.gb = off; off += n * p.Pl;
   s.gu = off; if (p.cplx) off += n * p.ldu * (p.kind == WIRE_KIND_WIRE2D ? 2 : 1);
-  s.S = gemm_tn_splits(n, p.Pl, p.first_gemm && p.Pin0 > p.P ? p.Pin0 : p.P, 64);
   const int64_t pn = p.first_gemm && p.Pin0 > p.P ? p.Pin0 : p.P;
-  s.slab = off; off += (int64_t)s.S * p.Pl * pn;
-  s.bslab = off; off += (int64_t)s.S * p.Pl;
+  if (p.m3) {
+    s.S = gemm3m_tn_splits(n, p.Kp, p.Kp, 64);
+    s.slab = off; off += (int64_t)s.S * 3 * p.Kp * p.Kp;
+    s.bslab = off; off += (int64_t)s.S * 2 * p.Kp;
+  } else {
+    s.S = gemm_tn_splits(n, p.Pl, (int)pn, 64);
+    s.slab = off; off += (int64_t)s.S * p.Pl * pn;
+    s.bslab = off; off += (int64_t)s.S * p.Pl;
+  }
   const int nbf = final_bwd_blocks(n);
   s.fpw = off; off += (int64_t)nbf * p.O * p.P;
   s.fpb = off; off += (int64_t)nbf * p.O + 64;
@@ -270,8 +290,12 @@ extern "C" int wire_pack_params(void* stream, const wire_net_desc* d, const void
     const float* c = p.per_layer == 4 ? (const float*)params[p.per_layer * l + 3] : nullptr;
     const int kin = (l == 0) ? p.Din : p.K;
     const int pin = (l == 0) ? p.Pin0 : p.P;
-    HIPCHK(launch_pack_hidden(s, p.kind, W, b, V, c, p.K, kin, p.P, pin, packed + p.off_fwd[l],
-                              packed + p.off_dg[l], packed + p.off_bias[l]));
+    if (p.m3)
+      HIPCHK(launch_pack3m(s, W, b, p.K, p.K, p.Kp, p.Kp, packed + p.off_fwd[l], packed + p.off_dg[l],
+                           packed + p.off_bias[l]));
+    else
+      HIPCHK(launch_pack_hidden(s, p.kind, W, b, V, c, p.K, kin, p.P, pin, packed + p.off_fwd[l],
+                                packed + p.off_dg[l], packed + p.off_bias[l]));
   }
   HIPCHK(launch_pack_final(s, p.kind, (const float*)params[p.ntens - 2],
                            (const float*)params[p.ntens - 1], p.K, p.P, p.O, packed + p.off_wf,
@@ -327,8 +351,12 @@ extern "C" int wire_mlp_fwd(void* stream, const wire_net_desc* d, const float* p
     GemmEpiParams ep; ep.bias = packed + p.off_bias[l]; ep.o0 = lin_l(l); ep.o1 = out_l(l);
     ep.ld0 = p.Pl; ep.ld1 = p.P; ep.omega = p.w; ep.scale = p.s; ep.kvalid = p.K;
     ProfScope ps(s, 0, 2.0 * n * p.Pl * p.P);
-    HIPCHK(launch_gemm_nt(s, epi_fwd(p.kind), out_l(l - 1), p.P, packed + p.off_fwd[l], p.P, n,
-                          p.Pl, p.P, ep));
+    if (p.m3)
+      HIPCHK(launch_gemm3m_nt(s, EPI_GABOR_FWD, out_l(l - 1), p.P, packed + p.off_fwd[l], p.P, n, p.Kp,
+                              p.Kp, ep));
+    else
+      HIPCHK(launch_gemm_nt(s, epi_fwd(p.kind), out_l(l - 1), p.P, packed + p.off_fwd[l], p.P, n,
+                            p.Pl, p.P, ep));
   }
   { ProfScope ps(s, 3, 0);
     HIPCHK(launch_final_fwd(s, out_l(p.L), n, p.P, p.O, packed + p.off_wf, packed + p.off_bf, y)); }
@@ -383,7 +411,14 @@ extern "C" int wire_mlp_bwd(void* stream, const wire_net_desc* d, const float* p
     float* gb = (float*)grads[p.per_layer * l + 1];
     float* gV = p.per_layer == 4 ? (float*)grads[p.per_layer * l + 2] : nullptr;
     float* gc = p.per_layer == 4 ? (float*)grads[p.per_layer * l + 3] : nullptr;
-    {
+    if (p.m3) {
+      const int S = sc.S;
+      { ProfScope ps(s, 2, 2.0 * n * p.Pl * p.P);
+        HIPCHK(launch_gemm3m_tn(s, gcur, p.P, out_l(l - 1), p.P, n, p.Kp, p.Kp, S, Sx + sc.slab,
+                                Sx + sc.bslab)); }
+      ProfScope ps(s, 3, 0);
+      HIPCHK(launch_wgrad3m_reduce(s, Sx + sc.slab, Sx + sc.bslab, S, p.K, p.K, p.Kp, p.Kp, gW, gb));
+    } else {
       const int S = gemm_tn_splits(n, p.Pl, p.P, sc.S);
       { ProfScope ps(s, 2, 2.0 * n * p.Pl * p.P);
         HIPCHK(launch_gemm_tn(s, gcur, p.Pl, out_l(l - 1), p.P, n, p.Pl, p.P, S, Sx + sc.slab,
@@ -408,7 +443,10 @@ extern "C" int wire_mlp_bwd(void* stream, const wire_net_desc* d, const float* p
     }
     if (!p.cplx && l == 1) ep.ld0 = p.P;
     { ProfScope ps(s, 1, 2.0 * n * p.Pl * p.P);
-      HIPCHK(launch_gemm_nt(s, epi, gcur, p.Pl, packed + p.off_dg[l], p.Pl, n, p.P, p.Pl, ep)); }
+      if (p.m3)
+        HIPCHK(launch_gemm3m_nt(s, epi, gcur, p.P, packed + p.off_dg[l], p.P, n, p.Kp, p.Kp, ep));
+      else
+        HIPCHK(launch_gemm_nt(s, epi, gcur, p.Pl, packed + p.off_dg[l], p.Pl, n, p.P, p.Pl, ep)); }
     float* t = gcur; gcur = gnext; gnext = t;
   }
 

@@ -72,3 +72,9 @@ hipError_t launch_mse_grad(hipStream_t s, const float* y, const float* target, c
                            float* loss_out, float* rec, float* partial);
 hipError_t launch_adam(hipStream_t s, float* p, const float* g, float* m, float* v, int64_t count,
                        float step_size, float beta1, float beta2, float eps, float inv_sqrt_bc2);
+
+// ---- 3M complex path: blocked-planar complex weight matrices + slab reduction
+hipError_t launch_pack3m(hipStream_t s, const float* W, const float* b, int K, int Kin, int Kp, int Kpin,
+                         float* Wb_fwd, float* Wb_dg, float* bias);
+hipError_t launch_wgrad3m_reduce(hipStream_t s, const float* slab, const float* bslab, int S, int K, int Kin,
+                                 int Kp_o, int Kp_i, float* gW, float* gb);

@@ -764,3 +764,71 @@ hipError_t launch_adam(hipStream_t s, float* p, const float* g, float* m, float*
                      (long long)count, step_size, beta1, beta2, eps, inv_sqrt_bc2);
   return hipGetLastError();
 }
+
+// ===========================================================================
+// 3M complex path (wire_gemm3m.hip): weights as blocked-planar complex matrices
+//   Wb_fwd[o][(i,re|im)] = W[o][i]            (lin = z W^T)
+//   Wb_dg [i][(o,re|im)] = conj(W[o][i])      (g_z = g_lin conj(W))
+// ===========================================================================
+__global__ void pack3m_kernel(const float* __restrict__ W, const float* __restrict__ b, int K, int Kin,
+                              int Kp, int Kpin, float* __restrict__ Wb_fwd, float* __restrict__ Wb_dg,
+                              float* __restrict__ bias) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // input feature (padded)
+  const int o = blockIdx.y;                              // output feature (padded)
+  if (i >= Kpin) return;
+  float wr = 0.f, wi = 0.f;
+  if (o < K && i < Kin) {
+    wr = W[((size_t)o * Kin + i) * 2];
+    wi = W[((size_t)o * Kin + i) * 2 + 1];
+  }
+  const int ci = blk_col(i, 0), co = blk_col(o, 0);
+  Wb_fwd[(size_t)o * (2 * Kpin) + ci] = wr;
+  Wb_fwd[(size_t)o * (2 * Kpin) + ci + 32] = wi;
+  Wb_dg[(size_t)i * (2 * Kp) + co] = wr;
+  Wb_dg[(size_t)i * (2 * Kp) + co + 32] = -wi;
+  if (i == 0) {
+    bias[co] = o < K ? b[2 * o] : 0.f;
+    bias[co + 32] = o < K ? b[2 * o + 1] : 0.f;
+  }
+}
+hipError_t launch_pack3m(hipStream_t s, const float* W, const float* b, int K, int Kin, int Kp, int Kpin,
+                         float* Wb_fwd, float* Wb_dg, float* bias) {
+  dim3 grid(cdiv(Kpin, 64), (unsigned)Kp);
+  hipLaunchKernelGGL(pack3m_kernel, grid, dim3(64), 0, s, W, b, K, Kin, Kp, Kpin, Wb_fwd, Wb_dg, bias);
+  return hipGetLastError();
+}
+
+// g_W.re = P1 + P2, g_W.im = P3 - P1 + P2 summed over the row splits; g_b from the column sums
+__global__ void wgrad3m_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab, int S,
+                                      int K, int Kin, int Kp_o, int Kp_i, float* __restrict__ gW,
+                                      float* __restrict__ gb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int o = blockIdx.y;
+  const size_t plane = (size_t)Kp_o * Kp_i;
+  if (i < Kin) {
+    float sr = 0.f, si = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float* p = slab + (size_t)s * 3 * plane + (size_t)o * Kp_i + i;
+      const float p1 = p[0], p2 = p[plane], p3 = p[2 * plane];
+      sr += p1 + p2;
+      si += (p3 - p1) + p2;
+    }
+    gW[((size_t)o * Kin + i) * 2] = sr;
+    gW[((size_t)o * Kin + i) * 2 + 1] = si;
+  }
+  if (i == 0) {
+    float br = 0.f, bi = 0.f;
+    for (int s = 0; s < S; ++s) {
+      br += bslab[((size_t)s * 2 + 0) * Kp_o + o];
+      bi += bslab[((size_t)s * 2 + 1) * Kp_o + o];
+    }
+    gb[2 * o] = br;
+    gb[2 * o + 1] = bi;
+  }
+}
+hipError_t launch_wgrad3m_reduce(hipStream_t s, const float* slab, const float* bslab, int S, int K, int Kin,
+                                 int Kp_o, int Kp_i, float* gW, float* gb) {
+  dim3 grid(cdiv(Kin, 64), (unsigned)K);
+  hipLaunchKernelGGL(wgrad3m_reduce_kernel, grid, dim3(64), 0, s, slab, bslab, S, K, Kin, Kp_o, Kp_i, gW, gb);
+  return hipGetLastError();
+}
