@@ -136,8 +136,8 @@ def main():
         n_gpu_batch = npts // world
         F = 24 * K * K * L + 4 * D * K + 12 * K * O      # SURVEY 8(d) algorithmic flop / sample
         value = npts * args.steps / dt
-        names = ["gemm_nt<gabor_fwd> (layer forward)", "gemm_nt<gabor_bwd> (data gradient)",
-                 "gemm_tn (weight gradient)", "other"]
+        names = ["gemm3m_nt<gabor_fwd> (layer forward)", "gemm3m_nt<gabor_bwd> (data gradient)",
+                 "gemm3m_tn (weight gradient)", "other"]
         alg_per_launch = 8.0 * K * K * (n_gpu_batch / max(1, args.micro_shards))   # per hidden-layer GEMM
         klass = max(range(3), key=lambda i: ms[i])
         avg_ms = ms[klass] / max(1, cnt[klass])

@@ -87,7 +87,11 @@ __global__ __launch_bounds__(256, 3) void gemm3m_nt_kernel(
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     const bool more = (kt + 1) < nk;
+#ifdef WIRE_ABLATE
+    if (more && !(ep.ablate & 1)) {
+#else
     if (more) {
+#endif
       const int c = slab_col(kt + 1);
       g_ar = *reinterpret_cast<const f32x4*>(a_src + c);
       g_ai = *reinterpret_cast<const f32x4*>(a_src + c + 32);
@@ -112,7 +116,11 @@ __global__ __launch_bounds__(256, 3) void gemm3m_nt_kernel(
         acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[s], bs[s], acc[2], 0, 0, 0);
       }
     }
+#ifdef WIRE_ABLATE
+    if (more && !(ep.ablate & 2)) {
+#else
     if (more) {
+#endif
       float* Aw = smem + (buf ^ 1) * (2 * T3M * LST);
       float* Bw = Aw + T3M * LST;
       *reinterpret_cast<f32x4*>(&Aw[st_off]) = g_ar;
@@ -120,6 +128,9 @@ __global__ __launch_bounds__(256, 3) void gemm3m_nt_kernel(
       *reinterpret_cast<f32x4*>(&Bw[st_off]) = g_br;
       *reinterpret_cast<f32x4*>(&Bw[st_off + 16]) = g_bi;
     }
+#ifdef WIRE_ABLATE
+    if (!(ep.ablate & 4))
+#endif
     __syncthreads();
   }
 

@@ -358,30 +358,38 @@ hipError_t launch_final_bwd(hipStream_t s, int kind, int raw, const float* g_y, 
 }
 
 // g_Wf = g_y^T conj(z):  re = sum g z_re, im = -sum g z_im;  g_bf = sum g + 0j
-__global__ void final_reduce_kernel(int kind, const float* __restrict__ part_w,
+// block = 64 columns x 4 partial groups (each group strides over the row blocks), LDS combine
+__global__ __launch_bounds__(256) void final_reduce_kernel(int kind, const float* __restrict__ part_w,
                                     const float* __restrict__ part_b, int nblk, int O, int K, int P,
                                     float* __restrict__ gWf, float* __restrict__ gbf) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float red[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + tx;
   const int o = blockIdx.y;
   const bool cplx = (kind == NK_WIRE || kind == NK_WIRE2D);
+  float sr = 0.f, si = 0.f;
   if (i < K) {
+    const int c = cplx ? blk_col(i, 0) : i;
+    for (int b = ty; b < nblk; b += 4) {
+      const float* pw = part_w + ((size_t)b * O + o) * P;
+      sr += pw[c];
+      if (cplx) si += pw[c + 32];
+    }
+  }
+  red[0][ty][tx] = sr;
+  red[1][ty][tx] = si;
+  __syncthreads();
+  if (ty == 0 && i < K) {
+    sr = (red[0][0][tx] + red[0][1][tx]) + (red[0][2][tx] + red[0][3][tx]);
+    si = (red[1][0][tx] + red[1][1][tx]) + (red[1][2][tx] + red[1][3][tx]);
     if (cplx) {
-      const int c = blk_col(i, 0);
-      float sr = 0.f, si = 0.f;
-      for (int b = 0; b < nblk; ++b) {
-        const float* pw = part_w + ((size_t)b * O + o) * P;
-        sr += pw[c];
-        si += pw[c + 32];
-      }
       gWf[((size_t)o * K + i) * 2] = sr;
       gWf[((size_t)o * K + i) * 2 + 1] = -si;
     } else {
-      float sr = 0.f;
-      for (int b = 0; b < nblk; ++b) sr += part_w[((size_t)b * O + o) * P + i];
       gWf[(size_t)o * K + i] = sr;
     }
   }
-  if (i == 0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     float sb = 0.f;
     for (int b = 0; b < nblk; ++b) sb += part_b[(size_t)b * O + o];
     if (cplx) { gbf[2 * o] = sb; gbf[2 * o + 1] = 0.f; } else gbf[o] = sb;
@@ -391,7 +399,7 @@ __global__ void final_reduce_kernel(int kind, const float* __restrict__ part_w,
 hipError_t launch_final_reduce(hipStream_t s, int kind, const float* part_w, const float* part_b,
                                int nblk, int O, int K, int P, float* gWf, float* gbf) {
   dim3 grid(cdiv(K, 64), (unsigned)O);
-  hipLaunchKernelGGL(final_reduce_kernel, grid, dim3(64), 0, s, kind, part_w, part_b, nblk, O, K, P,
+  hipLaunchKernelGGL(final_reduce_kernel, grid, dim3(256), 0, s, kind, part_w, part_b, nblk, O, K, P,
                      gWf, gbf);
   return hipGetLastError();
 }
@@ -467,50 +475,90 @@ hipError_t launch_wgrad_reduce(hipStream_t s, int kind, const float* slab, const
 
 // ===========================================================================
 // first-layer weight gradient: tall-skinny  G[n][C]^T [x | 1]
+//   stage 1: block = 64 column quads (float4) x 4 row lanes over CR_ROWS rows -> partial[blk][C][5]
+//   stage 2: block = 64 columns x 4 groups over the row blocks
 // ===========================================================================
-#define CR_ROWS 512
+#define CR_ROWS 256
 int colreduce_blocks(int64_t n) { return (int)((n + CR_ROWS - 1) / CR_ROWS); }
 
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ G, int ldg, int C,
                                                         const float* __restrict__ x, int D,
                                                         long long n, float* __restrict__ partial) {
-  const int c = blockIdx.y * blockDim.x + threadIdx.x;
+  __shared__ float red[4][64][20];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c0 = (blockIdx.y * 64 + tx) * 4;
   const long long r0 = (long long)blockIdx.x * CR_ROWS;
   long long r1 = r0 + CR_ROWS;
   if (r1 > n) r1 = n;
-  if (c >= C) return;
-  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  for (long long row = r0; row < r1; ++row) {
-    const float g = G[row * ldg + c];
-    for (int d = 0; d < D; ++d) acc[d] = __builtin_fmaf(g, x[row * D + d], acc[d]);
-    acc[4] += g;
-  }
-  float* p = partial + ((size_t)blockIdx.x * C + c) * 5;
+  float acc[4][5];
 #pragma unroll
-  for (int d = 0; d < 5; ++d) p[d] = acc[d];
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int d = 0; d < 5; ++d) acc[q][d] = 0.f;
+  if (c0 < ldg) {
+    for (long long row = r0 + ty; row < r1; row += 4) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(G + row * ldg + c0);
+      float xv[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int d = 0; d < D; ++d) xv[d] = x[row * D + d];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc[q][d] = __builtin_fmaf(g[q], xv[d], acc[q][d]);
+        acc[q][4] += g[q];
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int d = 0; d < 5; ++d) red[ty][tx][q * 5 + d] = acc[q][d];
+  __syncthreads();
+  if (ty == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = c0 + q;
+      if (c < C) {
+        float* p = partial + ((size_t)blockIdx.x * C + c) * 5;
+#pragma unroll
+        for (int d = 0; d < 5; ++d)
+          p[d] = (red[0][tx][q * 5 + d] + red[1][tx][q * 5 + d]) + (red[2][tx][q * 5 + d] + red[3][tx][q * 5 + d]);
+      }
+    }
+  }
 }
 
-__global__ void colreduce_final_kernel(const float* __restrict__ partial, int nblk, int C, int D,
-                                       float* __restrict__ gW0, float* __restrict__ gb0) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ partial, int nblk,
+                                                              int C, int D, float* __restrict__ gW0,
+                                                              float* __restrict__ gb0) {
+  __shared__ float red[4][64][5];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
   float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int b = 0; b < nblk; ++b) {
-    const float* p = partial + ((size_t)b * C + c) * 5;
+  if (c < C) {
+    for (int b = ty; b < nblk; b += 4) {
+      const float* p = partial + ((size_t)b * C + c) * 5;
 #pragma unroll
-    for (int d = 0; d < 5; ++d) acc[d] += p[d];
+      for (int d = 0; d < 5; ++d) acc[d] += p[d];
+    }
   }
-  for (int d = 0; d < D; ++d) gW0[c * D + d] = acc[d];
-  gb0[c] = acc[4];
+#pragma unroll
+  for (int d = 0; d < 5; ++d) red[ty][tx][d] = acc[d];
+  __syncthreads();
+  if (ty == 0 && c < C) {
+#pragma unroll
+    for (int d = 0; d < 5; ++d) acc[d] = (red[0][tx][d] + red[1][tx][d]) + (red[2][tx][d] + red[3][tx][d]);
+    for (int d = 0; d < D; ++d) gW0[c * D + d] = acc[d];
+    gb0[c] = acc[4];
+  }
 }
 
 hipError_t launch_colreduce(hipStream_t s, const float* G, int ldg, int C, const float* x, int D,
                             int64_t n, float* partial, float* gW0, float* gb0) {
-  if (D > 4) return hipErrorInvalidValue;
+  if (D > 4 || (ldg & 3)) return hipErrorInvalidValue;
   const int nblk = colreduce_blocks(n);
   dim3 grid((unsigned)nblk, cdiv(C, 256));
   hipLaunchKernelGGL(colreduce_kernel, grid, dim3(256), 0, s, G, ldg, C, x, D, (long long)n, partial);
-  hipLaunchKernelGGL(colreduce_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, partial, nblk, C, D,
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3(cdiv(C, 64)), dim3(256), 0, s, partial, nblk, C, D,
                      gW0, gb0);
   return hipGetLastError();
 }
