@@ -74,15 +74,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU.  (Rehearsal on a 1-GPU box: WIRE_BENCH_BACKEND=gloo lets several ranks
+    # share cuda:0 -- RCCL itself refuses two ranks on one device.)
+    ndev = max(1, torch.cuda.device_count())
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
+    backend = os.environ.get("WIRE_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
 
     from wire_amd import _lib
     from wire_amd.modules import models
@@ -127,7 +133,7 @@ def main():
     fl = (C.c_double * 4)()
     lib.wire_prof_read(ms, cnt, fl)
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     final_loss = float(loss.item())

@@ -60,6 +60,10 @@ int main(int argc, char** argv) {
       {"3M nt gabor_bwd", 2, EPI_GABOR_BWD, 0, 0},  {"3M tn wgrad", 3, 0, 0, 0},
       {"3M store noglobal", 2, EPI_STORE, 0, 1},    {"3M store nog+nolds", 2, EPI_STORE, 0, 3},
       {"3M store nobarrier", 2, EPI_STORE, 0, 4},   {"3M store mfma only", 2, EPI_STORE, 0, 7},
+      {"3M fwd 3WG/CU", 2, EPI_GABOR_FWD, 0, 12 << 8}, {"3M fwd 2WG/CU", 2, EPI_GABOR_FWD, 0, 36 << 8},
+      {"3M fwd 1WG/CU", 2, EPI_GABOR_FWD, 0, 100 << 8}, {"3M mfma-only 1WG/CU", 2, EPI_STORE, 0, (100 << 8) | 7},
+      {"3M mfma-only 2WG/CU", 2, EPI_STORE, 0, (36 << 8) | 7},
+
   };
   std::vector<double> best(vars.size(), 1e30), sum(vars.size(), 0);
   for (int r = 0; r < rounds + 1; ++r) {
@@ -89,7 +93,7 @@ int main(int argc, char** argv) {
          (long long)N, P, flop / 1e9);
   for (size_t v = 0; v < vars.size(); ++v) {
     const double tf = flop / (sum[v] / rounds * 1e-3) / 1e12;
-    const double mf = (vars[v].kind >= 2 ? 0.75 : 1.0) * tf;
+    const double mf = (vars[v].kind >= 2 ? 0.75 : 1.0) * tf;   // 3M kinds execute 0.75x the flops
     printf("  %-22s mean %7.3f ms  min %7.3f ms  -> %6.1f alg TF (%5.1f%%)   MFMA busy %5.1f%%\n",
            vars[v].name, sum[v] / rounds, best[v], tf, 100.0 * tf / 157.3, 100.0 * mf / 157.3);
   }

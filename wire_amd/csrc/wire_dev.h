@@ -71,6 +71,36 @@ WIRE_DEVINL void gabor_fwd(float u, float v, float w0, float s0, float& o_re, fl
   o_re = e * cs;
   o_im = e * sn;
 }
+// ---- lean variants for the GEMM epilogues -----------------------------------------------
+// On gfx950 v_mfma_f32_32x32x2_f32 and fp32 VALU instructions do NOT overlap (measured with
+// tools/mfma_valu_probe.hip: every v_fma beside the MFMA stream costs ~5 cycles of it, every
+// v_exp/v_sin ~9), so an epilogue instruction is paid for in matrix-core time.  These versions
+// use the hardware transcendental unit (v_sin/v_cos take revolutions) with a two-term 1/(2 pi)
+// reduction: max abs error 4e-7 for |x| <= 200 (tools/trig_probe.hip) against 9e-8 for the
+// polynomial path -- far inside the 1e-5 per-layer parity bar -- at a third of the issue cost.
+WIRE_DEVINL void wire_sincos_hw(float x, float& sn, float& cs) {
+  const float INV2PI_HI = 0.15915494f;       // float(1 / 2 pi)
+  const float INV2PI_LO = 6.42063833e-9f;    // 1 / 2 pi - INV2PI_HI
+  const float t = x * INV2PI_HI;
+  float e = __builtin_fmaf(x, INV2PI_HI, -t);
+  e = __builtin_fmaf(x, INV2PI_LO, e);
+  const float r = __builtin_amdgcn_fractf(t) + e;
+  sn = __builtin_amdgcn_sinf(r);
+  cs = __builtin_amdgcn_cosf(r);
+}
+// neg_s2 = -s0^2, w0l2e = w0 * log2(e), ns2l2e = -s0^2 * log2(e): the envelope exponent is formed
+// directly in the base-2 domain (one v_exp_f32, no compensation: error <= 2.4e-7 of max(1, value)).
+WIRE_DEVINL void gabor_fwd_lean(float u, float v, float w0, float w0l2e, float ns2l2e, float& o_re,
+                                float& o_im) {
+  const float q = __builtin_fmaf(u, u, v * v);
+  const float t = __builtin_fmaf(ns2l2e, q, -(w0l2e * v));   // log2 of the envelope
+  const float e = __builtin_amdgcn_exp2f(t);
+  float sn, cs;
+  wire_sincos_hw(w0 * u, sn, cs);
+  o_re = e * cs;
+  o_im = e * sn;
+}
+
 // first layer: lin is real (v = 0)
 WIRE_DEVINL void gabor_fwd_real(float u, float w0, float s0, float& o_re, float& o_im) {
   float su = s0 * u;

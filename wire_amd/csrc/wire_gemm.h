@@ -57,6 +57,7 @@ hipError_t launch_gemm_tn(hipStream_t s, const float* G, int ldg, const float* Z
 // NT: C[M][Kp_out] = A[M][Kp_in] * B[Kp_out][Kp_in]^T, all blocked-planar complex rows.
 hipError_t launch_gemm3m_nt(hipStream_t s, int epi, const float* A, int lda, const float* B, int ldb,
                             int64_t M, int Kp_out, int Kp_in, const GemmEpiParams& ep);
+int gemm3m_tune_set(const char* key, int value);
 // TN: slab[split][3][Kp_o][Kp_i] planes (P1,P2,P3), bslab[split][2][Kp_o] column sums of G (re, im)
 int gemm3m_tn_splits(int64_t n, int Kp_o, int Kp_i, int max_splits);
 hipError_t launch_gemm3m_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n,

@@ -2,23 +2,30 @@
 // (Gauss / "3M") complex product on fp32 MFMA: 6 real flop per complex MAC on the
 // matrix cores instead of 8.
 //
-//   forward / data gradient (NT):   lin = z * W^T      (W given as a blocked-planar matrix)
-//       T1 = (z_re + z_im) W_re,  T2 = z_re (W_im - W_re),  T3 = z_im (W_re + W_im)
-//       lin_re = T1 - T3,  lin_im = T1 + T2
+//   forward / data gradient (NT):   C = A * B^T      (A, C blocked-planar complex rows)
+//       T1 = (a_re + a_im) b_re,  T2 = a_re (b_im - b_re),  T3 = a_im (b_re + b_im)
+//       C_re = T1 - T3,  C_im = T1 + T2
 //   weight gradient (TN):           g_W = g^T conj(z)
 //       P1 = g_re^T z_re,  P2 = g_im^T z_im,  P3 = (g_re + g_im)^T (z_re - z_im)
 //       g_W.re = P1 + P2,  g_W.im = P3 - P1 + P2
 //
-// The sums / differences are formed in registers from the LDS fragments (one VALU
-// op per MFMA), so HBM and LDS hold exactly the same two planes (re, im) as the
-// 4-multiplication kernels and the byte traffic per complex MAC is unchanged.
+// VALU budget.  On gfx950 v_mfma_f32_32x32x2_f32 and fp32 VALU instructions do not
+// overlap (tools/mfma_valu_probe.hip: ~5 matrix-pipe cycles per v_fma, ~9 per
+// v_exp/v_sin, for any number of waves per SIMD), so these kernels are bound by
+// 64 * #MFMA + 5 * #VALU and every vector instruction is treated as a cost:
+//   * the three operand combinations of the 3M product are formed in registers from
+//     the LDS fragments (one VALU op per MFMA).  Precomputing the weight-side ones
+//     into a third weight plane was measured SLOWER (+6 %): the extra LDS plane
+//     costs a workgroup of occupancy (3 instead of 4 per CU);
+//   * the epilogue uses the hardware transcendental unit (wire_dev.h
+//     gabor_fwd_lean), uniform (SGPR) base pointers with one 32-bit byte offset
+//     per accumulator row, and a branch-free fast path for full tiles.
 //
 // Tiling: 64 rows x 64 complex features per 256-thread workgroup, 4 waves of
 // 32 x 32, three 32x32 accumulators (T1,T2,T3) per wave; reduction slabs of 16
-// complex features (two 64-byte segments per row), double-buffered LDS
-// (36 KB -> 4 workgroups per CU), rows padded to 36 floats (conflict-free
-// ds_read_b128).  Replaces the ATen complex addmm / mm of modules/wire.py:89 and
-// of its autograd backward.
+// complex indices, double-buffered LDS (36 KB -> 4 workgroups per CU), rows
+// padded to 36 floats (conflict-free ds_read_b128).  Replaces the
+// ATen complex addmm / mm of modules/wire.py:89 and of its autograd backward.
 #include <cstdlib>
 #include <cstring>
 
@@ -27,13 +34,15 @@
 
 #define T3M 64          // rows and complex features per workgroup tile
 #define KC 16           // complex reduction indices per slab
-#define LST 36          // LDS row stride (16 re + 16 im + 4 pad)
+#define LSTA 36         // LDS row stride of A: 16 re + 16 im + 4 pad
+#define LSTB 36         // LDS row stride of B: 16 re + 16 im + 4 pad
+#define BUF3M (T3M * LSTA + T3M * LSTB)
 
 template <int EPI>
-__global__ __launch_bounds__(256, 3) void gemm3m_nt_kernel(
+__global__ __launch_bounds__(256, 4) void gemm3m_nt_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int M, int Kp_out,
     int Kp_in, int tiles_m, int tiles_n, GemmEpiParams ep) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * T3M * LST];
+  __shared__ __attribute__((aligned(16))) float smem[2 * BUF3M];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wave_m = wave >> 1, wave_n = wave & 1;
@@ -47,14 +56,15 @@ __global__ __launch_bounds__(256, 3) void gemm3m_nt_kernel(
   const int m_base = rt * T3M;
   const int f_base = ct * T3M;                 // first output feature of the tile
 
-  // loader: thread -> (row 0..63, 16-byte chunk 0..3); 4 float4 per slab (A re, A im, B re, B im)
+  // loader: thread -> (row 0..63, 16-byte chunk 0..3): A re, A im, B re, B im
   const int lrow = tid >> 2;
   const int lc4 = (tid & 3) * 4;
   int ra = m_base + lrow; ra = ra < M ? ra : M - 1;
   int rb = f_base + lrow; rb = rb < Kp_out ? rb : Kp_out - 1;
   const float* a_src = A + (size_t)ra * lda + lc4;
   const float* b_src = B + (size_t)rb * ldb + lc4;
-  const int st_off = lrow * LST + lc4;
+  const int sta = lrow * LSTA + lc4;
+  const int stb = T3M * LSTA + lrow * LSTB + lc4;
 
   f32x16 acc[3];
 #pragma unroll
@@ -62,27 +72,25 @@ __global__ __launch_bounds__(256, 3) void gemm3m_nt_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  const int nk = Kp_in / KC;                   // slabs; slab s covers features [16 s, 16 s + 16)
-  auto slab_col = [](int s) { return ((s >> 1) << 6) + ((s & 1) << 4); };   // column of the re segment
+  const int nk = Kp_in / KC;                   // slab s covers reduction indices [16 s, 16 s + 16)
+  // column of the slab's re segment in a blocked-planar row (the im segment is 32 floats on)
+  auto cola = [](int s) { return ((s >> 1) << 6) + ((s & 1) << 4); };
 
   f32x4 g_ar, g_ai, g_br, g_bi;
   {
-    const int c = slab_col(0);
-    g_ar = *reinterpret_cast<const f32x4*>(a_src + c);
-    g_ai = *reinterpret_cast<const f32x4*>(a_src + c + 32);
-    g_br = *reinterpret_cast<const f32x4*>(b_src + c);
-    g_bi = *reinterpret_cast<const f32x4*>(b_src + c + 32);
-    float* As = smem;
-    float* Bs = smem + T3M * LST;
-    *reinterpret_cast<f32x4*>(&As[st_off]) = g_ar;
-    *reinterpret_cast<f32x4*>(&As[st_off + 16]) = g_ai;
-    *reinterpret_cast<f32x4*>(&Bs[st_off]) = g_br;
-    *reinterpret_cast<f32x4*>(&Bs[st_off + 16]) = g_bi;
+    g_ar = *reinterpret_cast<const f32x4*>(a_src);
+    g_ai = *reinterpret_cast<const f32x4*>(a_src + 32);
+    g_br = *reinterpret_cast<const f32x4*>(b_src);
+    g_bi = *reinterpret_cast<const f32x4*>(b_src + 32);
+    *reinterpret_cast<f32x4*>(&smem[sta]) = g_ar;
+    *reinterpret_cast<f32x4*>(&smem[sta + 16]) = g_ai;
+    *reinterpret_cast<f32x4*>(&smem[stb]) = g_br;
+    *reinterpret_cast<f32x4*>(&smem[stb + 16]) = g_bi;
   }
   __syncthreads();
 
-  const int a_rd = (wave_m * 32 + l31) * LST + 4 * h;
-  const int b_rd = (wave_n * 32 + l31) * LST + 4 * h;
+  const int a_rd = (wave_m * 32 + l31) * LSTA + 4 * h;
+  const int b_rd = T3M * LSTA + (wave_n * 32 + l31) * LSTB + 4 * h;
 
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
@@ -92,20 +100,19 @@ __global__ __launch_bounds__(256, 3) void gemm3m_nt_kernel(
 #else
     if (more) {
 #endif
-      const int c = slab_col(kt + 1);
-      g_ar = *reinterpret_cast<const f32x4*>(a_src + c);
-      g_ai = *reinterpret_cast<const f32x4*>(a_src + c + 32);
-      g_br = *reinterpret_cast<const f32x4*>(b_src + c);
-      g_bi = *reinterpret_cast<const f32x4*>(b_src + c + 32);
+      const int ca = cola(kt + 1);
+      g_ar = *reinterpret_cast<const f32x4*>(a_src + ca);
+      g_ai = *reinterpret_cast<const f32x4*>(a_src + ca + 32);
+      g_br = *reinterpret_cast<const f32x4*>(b_src + ca);
+      g_bi = *reinterpret_cast<const f32x4*>(b_src + ca + 32);
     }
-    const float* As = smem + buf * (2 * T3M * LST);
-    const float* Bs = As + T3M * LST;
+    const float* S = smem + buf * BUF3M;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const f32x4 ar = *reinterpret_cast<const f32x4*>(&As[a_rd + 8 * q]);
-      const f32x4 ai = *reinterpret_cast<const f32x4*>(&As[a_rd + 16 + 8 * q]);
-      const f32x4 br = *reinterpret_cast<const f32x4*>(&Bs[b_rd + 8 * q]);
-      const f32x4 bi = *reinterpret_cast<const f32x4*>(&Bs[b_rd + 16 + 8 * q]);
+      const f32x4 ar = *reinterpret_cast<const f32x4*>(&S[a_rd + 8 * q]);
+      const f32x4 ai = *reinterpret_cast<const f32x4*>(&S[a_rd + 16 + 8 * q]);
+      const f32x4 br = *reinterpret_cast<const f32x4*>(&S[b_rd + 8 * q]);
+      const f32x4 bi = *reinterpret_cast<const f32x4*>(&S[b_rd + 16 + 8 * q]);
       const f32x4 as = ar + ai;
       const f32x4 bd = bi - br;
       const f32x4 bs = br + bi;
@@ -121,12 +128,11 @@ __global__ __launch_bounds__(256, 3) void gemm3m_nt_kernel(
 #else
     if (more) {
 #endif
-      float* Aw = smem + (buf ^ 1) * (2 * T3M * LST);
-      float* Bw = Aw + T3M * LST;
-      *reinterpret_cast<f32x4*>(&Aw[st_off]) = g_ar;
-      *reinterpret_cast<f32x4*>(&Aw[st_off + 16]) = g_ai;
-      *reinterpret_cast<f32x4*>(&Bw[st_off]) = g_br;
-      *reinterpret_cast<f32x4*>(&Bw[st_off + 16]) = g_bi;
+      float* Wd = smem + (buf ^ 1) * BUF3M;
+      *reinterpret_cast<f32x4*>(&Wd[sta]) = g_ar;
+      *reinterpret_cast<f32x4*>(&Wd[sta + 16]) = g_ai;
+      *reinterpret_cast<f32x4*>(&Wd[stb]) = g_br;
+      *reinterpret_cast<f32x4*>(&Wd[stb + 16]) = g_bi;
     }
 #ifdef WIRE_ABLATE
     if (!(ep.ablate & 4))
@@ -135,12 +141,16 @@ __global__ __launch_bounds__(256, 3) void gemm3m_nt_kernel(
   }
 
   // ------------------------------------------------------------------ epilogue
-  // lane holds, for feature f = f_w + l31 and 16 rows, T1/T2/T3 -> (re, im)
+  // lane holds, for feature f = f_w + l31 and 16 rows, T1/T2/T3 -> (re, im).
+  // Row of accumulator register r: m_w + 4 h + (r & 3) + 8 (r >> 2).
   const int m_w = m_base + wave_m * 32;
-  const int feat = f_base + wave_n * 32 + l31;
-  if (f_base + wave_n * 32 >= Kp_out) return;
+  const int f_w = f_base + wave_n * 32;
+  if (f_w >= Kp_out) return;
+  const int feat = f_w + l31;
   const int c_re = ((feat >> 5) << 6) + (feat & 31);
   const int c_im = c_re + 32;
+  // fast path: every row of the tile exists and every feature of the wave is a real one
+  const bool full = (m_base + T3M <= M) && (f_w + 32 <= ep.kvalid);
 
   if constexpr (EPI == EPI_STORE) {
 #pragma unroll
@@ -153,37 +163,96 @@ __global__ __launch_bounds__(256, 3) void gemm3m_nt_kernel(
     }
   } else if constexpr (EPI == EPI_GABOR_FWD) {
     const float b_re = ep.bias[c_re], b_im = ep.bias[c_im];
-    const bool valid = feat < ep.kvalid;
+    if (full) {
+      // uniform bases + one 32-bit byte offset per row (ld0 == ld1 is checked by the launcher)
+      char* __restrict__ lin_b = reinterpret_cast<char*>(ep.o0);
+      char* __restrict__ out_b = reinterpret_cast<char*>(ep.o1);
+      const unsigned ldb4 = (unsigned)ep.ld1 * 4u;
+      const unsigned off0 = (unsigned)(m_w + 4 * h) * ldb4 + (unsigned)c_re * 4u;
+      const float w0 = ep.omega;
+      const float w0l2e = ep.omega * 1.44269502f;
+      const float ns2l2e = -(ep.scale * ep.scale) * 1.44269502f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m_w + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float u = (acc[0][r] - acc[2][r]) + b_re;
-      const float v = (acc[0][r] + acc[1][r]) + b_im;
-      float o_re, o_im;
-      gabor_fwd(u, v, ep.omega, ep.scale, o_re, o_im);
-      if (!valid) { o_re = 0.f; o_im = 0.f; }
-      if (row < M) {
-        if (ep.o0) {
-          ep.o0[(size_t)row * ep.ld0 + c_re] = u;
-          ep.o0[(size_t)row * ep.ld0 + c_im] = v;
+      for (int r = 0; r < 16; ++r) {
+        const unsigned off = off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * ldb4;
+        const float u = (acc[0][r] - acc[2][r]) + b_re;
+        const float v = (acc[0][r] + acc[1][r]) + b_im;
+        float o_re, o_im;
+        gabor_fwd_lean(u, v, w0, w0l2e, ns2l2e, o_re, o_im);
+        if (lin_b) {
+          *reinterpret_cast<float*>(lin_b + off) = u;
+          *reinterpret_cast<float*>(lin_b + off + 128) = v;
         }
-        ep.o1[(size_t)row * ep.ld1 + c_re] = o_re;
-        ep.o1[(size_t)row * ep.ld1 + c_im] = o_im;
+        *reinterpret_cast<float*>(out_b + off) = o_re;
+        *reinterpret_cast<float*>(out_b + off + 128) = o_im;
+      }
+    } else {
+      const bool valid = feat < ep.kvalid;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m_w + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float u = (acc[0][r] - acc[2][r]) + b_re;
+        const float v = (acc[0][r] + acc[1][r]) + b_im;
+        float o_re, o_im;
+        gabor_fwd(u, v, ep.omega, ep.scale, o_re, o_im);
+        if (!valid) { o_re = 0.f; o_im = 0.f; }
+        if (row < M) {
+          if (ep.o0) {
+            ep.o0[(size_t)row * ep.ld0 + c_re] = u;
+            ep.o0[(size_t)row * ep.ld0 + c_im] = v;
+          }
+          ep.o1[(size_t)row * ep.ld1 + c_re] = o_re;
+          ep.o1[(size_t)row * ep.ld1 + c_im] = o_im;
+        }
       }
     }
   } else if constexpr (EPI == EPI_GABOR_BWD) {
     const float m2s2 = -2.f * ep.scale * ep.scale;
+    if (m_base + T3M <= M) {
+      const char* __restrict__ lin_b = reinterpret_cast<const char*>(ep.i0);
+      const char* __restrict__ out_b = reinterpret_cast<const char*>(ep.i1);
+      char* __restrict__ gl_b = reinterpret_cast<char*>(ep.o0);
+      const unsigned ldb4 = (unsigned)ep.ld0 * 4u;
+      const unsigned off0 = (unsigned)(m_w + 4 * h) * ldb4 + (unsigned)c_re * 4u;
+      const float w0 = ep.omega;
+      // two batches of 8 rows: issue the 32 loads of a batch, then consume them
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m_w + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < M) {
-        const size_t o0 = (size_t)row * ep.ld0, o1 = (size_t)row * ep.ld1;
-        const float u = ep.i0[o0 + c_re], v = ep.i0[o0 + c_im];
-        const float pr = ep.i1[o1 + c_re], pi = ep.i1[o1 + c_im];
-        float gl_re, gl_im;
-        gabor_bwd(acc[0][r] - acc[2][r], acc[0][r] + acc[1][r], u, v, pr, pi, ep.omega, m2s2, gl_re, gl_im);
-        ep.o0[o0 + c_re] = gl_re;
-        ep.o0[o0 + c_im] = gl_im;
+      for (int rb0 = 0; rb0 < 16; rb0 += 8) {
+        float lu[8], lv[8], pr[8], pi[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = rb0 + j;
+          const unsigned off = off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * ldb4;
+          lu[j] = *reinterpret_cast<const float*>(lin_b + off);
+          lv[j] = *reinterpret_cast<const float*>(lin_b + off + 128);
+          pr[j] = *reinterpret_cast<const float*>(out_b + off);
+          pi[j] = *reinterpret_cast<const float*>(out_b + off + 128);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = rb0 + j;
+          const unsigned off = off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * ldb4;
+          const float gr = acc[0][r] - acc[2][r], gi = acc[0][r] + acc[1][r];
+          const float c_r = __builtin_fmaf(pr[j], gr, pi[j] * gi);
+          const float c_i = __builtin_fmaf(pr[j], gi, -(pi[j] * gr));
+          const float t = m2s2 * c_r;
+          *reinterpret_cast<float*>(gl_b + off) = __builtin_fmaf(t, lu[j], w0 * c_i);
+          *reinterpret_cast<float*>(gl_b + off + 128) = __builtin_fmaf(t, lv[j], -(w0 * c_r));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m_w + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < M) {
+          const size_t o0 = (size_t)row * ep.ld0, o1 = (size_t)row * ep.ld1;
+          const float u = ep.i0[o0 + c_re], v = ep.i0[o0 + c_im];
+          const float pr = ep.i1[o1 + c_re], pi = ep.i1[o1 + c_im];
+          float gl_re, gl_im;
+          gabor_bwd(acc[0][r] - acc[2][r], acc[0][r] + acc[1][r], u, v, pr, pi, ep.omega, m2s2, gl_re, gl_im);
+          ep.o0[o0 + c_re] = gl_re;
+          ep.o0[o0 + c_im] = gl_im;
+        }
       }
     }
   } else if constexpr (EPI == EPI_GABOR_BWD_FIRST) {
@@ -216,16 +285,27 @@ static hipError_t launch3m_t(hipStream_t s, const float* A, int lda, const float
   const int tiles_m = (int)((M + T3M - 1) / T3M);
   const int tiles_n = (Kp_out + T3M - 1) / T3M;
   const int tiles_m_pad = (tiles_m + 7) & ~7;
-  hipLaunchKernelGGL((gemm3m_nt_kernel<EPI>), dim3((unsigned)(tiles_m_pad * tiles_n)), dim3(256), 0, s, A,
+#ifdef WIRE_ABLATE
+  const size_t dyn = (size_t)((ep.ablate >> 8) & 0xff) * 1024;   // occupancy experiments: pad LDS per WG
+#else
+  const size_t dyn = 0;
+#endif
+  hipLaunchKernelGGL((gemm3m_nt_kernel<EPI>), dim3((unsigned)(tiles_m_pad * tiles_n)), dim3(256), dyn, s, A,
                      lda, B, ldb, (int)M, Kp_out, Kp_in, tiles_m, tiles_n, ep);
   return hipGetLastError();
 }
 
-// C[M][Kp_out complex, blocked planar] = A[M][Kp_in complex] * B[Kp_out][Kp_in complex]^T
+int gemm3m_tune_set(const char* key, int value) { (void)key; (void)value; return -1; }
+
+// C[M][Kp_out] = A[M][Kp_in] * B[Kp_out][Kp_in]^T, all blocked-planar complex rows (launch_pack3m
+// writes W and conj(W)^T in that layout).
 hipError_t launch_gemm3m_nt(hipStream_t s, int epi, const float* A, int lda, const float* B, int ldb,
                             int64_t M, int Kp_out, int Kp_in, const GemmEpiParams& ep) {
   if (M <= 0) return hipSuccess;
   if ((Kp_out & 31) || (Kp_in & 31) || (lda & 3) || (ldb & 3) || M > 0x7fffff00LL) return hipErrorInvalidValue;
+  // the fast epilogues share one row offset between their buffers and use 32-bit byte offsets
+  if ((epi == EPI_GABOR_FWD || epi == EPI_GABOR_BWD) && ep.ld0 != ep.ld1) return hipErrorInvalidValue;
+  if ((double)M * (double)(ep.ld1 > ep.ld0 ? ep.ld1 : ep.ld0) * 4.0 >= 4294967296.0) return hipErrorInvalidValue;
   switch (epi) {
     case EPI_STORE: return launch3m_t<EPI_STORE>(s, A, lda, B, ldb, M, Kp_out, Kp_in, ep);
     case EPI_GABOR_FWD: return launch3m_t<EPI_GABOR_FWD>(s, A, lda, B, ldb, M, Kp_out, Kp_in, ep);

@@ -60,7 +60,10 @@ class FlatGradAllReducer:
         else:
             self.buckets = [(o, min(n, o + bucket_floats)) for o in range(0, n, bucket_floats)]
         self.stream = None
-        if self.active and flat.is_cuda and use_side_stream:
+        # gloo cannot reduce device tensors: stage through pinned host memory (rehearsal only;
+        # the production backend is RCCL, which reduces the device buffer in place)
+        self.stage_host = bool(self.active and flat.is_cuda and dist.get_backend(group) == "gloo")
+        if self.active and flat.is_cuda and use_side_stream and not self.stage_host:
             self.stream = torch.cuda.Stream(device=flat.device)
         self._pending: List = []
 
@@ -69,6 +72,11 @@ class FlatGradAllReducer:
         if not self.active:
             return
         t = self.flat if tensor is None else tensor
+        if self.stage_host:
+            host = t.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(host)
+            return
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(t.device))
             with torch.cuda.stream(self.stream):
