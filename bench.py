@@ -43,11 +43,24 @@ OMEGA0, SIGMA0 = 20.0, 30.0
 SIDE = 512                      # 512 x 512 = 262 144 coordinates per GPU
 
 
+def host_cores() -> int:
+    """CPU cores this process may actually use: min(affinity, cgroup quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(n_sample: int, iters: int):
     """Reference CPU path (eager PyTorch restatement from oracle/) on a bounded
     sample: fwd + bwd + Adam over n_sample coordinates of the same workload."""
     from oracle import torch_ref, wire_oracle as wo
-    cores = torch.get_num_threads()
+    cores = host_cores()
+    torch.set_num_threads(cores)
     p = torch_ref.init_wire_params(D, HIDDEN_FEATURES, L, O, seed=0)
     coords = torch.tensor(wo.image_coords(SIDE, SIDE))[:n_sample][None]
     g = torch.Generator().manual_seed(0)
@@ -61,6 +74,47 @@ def cpu_baseline(n_sample: int, iters: int):
                       f"4x256 complex WIRE, torch {torch.__version__} CPU eager (oracle/torch_ref.py)"}
 
 
+def extras(dev, lib):
+    """Secondary numbers (not the headline): the same net through the reference's API width
+    (hidden_features=256 -> K=181, padded to 192 on the matrix cores) and forward-only inference."""
+    from wire_amd.modules import models
+    from wire_amd.trainer import FusedTrainer
+    res = {}
+    g = torch.Generator().manual_seed(0)
+    target = torch.rand(SIDE * SIDE, O, generator=g)
+    for tag, hf in (("k181_api_hidden_features_256", 256), ("k256_literal", HIDDEN_FEATURES)):
+        torch.manual_seed(0)
+        model = models.get_INR(nonlin="wire", in_features=D, out_features=O, hidden_features=hf,
+                               hidden_layers=L, first_omega_0=OMEGA0, hidden_omega_0=OMEGA0, scale=SIGMA0).to(dev)
+        K = model._arch["width"]
+        tr = FusedTrainer(model, (SIDE, SIDE), target, lr=5e-3, niters=2000)
+        if hf == 256:
+            for _ in range(2):
+                tr.step(torch.randperm(SIDE * SIDE, device=dev))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                tr.step(torch.randperm(SIDE * SIDE, device=dev))
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 10
+            F = 24 * K * K * L + 4 * D * K + 12 * K * O
+            res[tag] = {"train_samples_per_s": SIDE * SIDE / dt, "K": K,
+                        "frac_of_fp32_mfma_peak": SIDE * SIDE / dt * F / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+        else:
+            tr.render()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                tr.render()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 5
+            Ff = 8 * K * K * L + 2 * D * K + 4 * K * O
+            res["forward_only_" + tag] = {"samples_per_s": SIDE * SIDE / dt, "K": K,
+                                          "frac_of_fp32_mfma_peak": SIDE * SIDE / dt * Ff / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+        del tr, model
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,6 +122,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--micro-shards", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--hidden-features", type=int, default=HIDDEN_FEATURES)
     args = ap.parse_args()
 
@@ -174,8 +229,10 @@ def main():
             "kernel_ms_per_step": {names[i]: ms[i] / args.steps for i in range(4)},
             "final_loss": final_loss,
         }
+        if world == 1 and not args.no_extras:
+            out["extras"] = extras(dev, lib)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(16384, 2)
+            out["cpu_baseline"] = cpu_baseline(32768, 2)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

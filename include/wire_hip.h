@@ -160,6 +160,17 @@ int wire_adam_step_flat(void* stream, float* param, const float* grad,
                         float lr, float beta1, float beta2, float eps,
                         int64_t step);
 
+/* Evaluation metrics without a device->host copy of the reconstruction
+ * (the reference copies the whole image to the host every epoch,
+ * wire_image_denoise.py:161-178, and binarises the volume on the host side,
+ * modules/volutils.py:74-91).  out2 / partial: device; partial >= 2048 floats.
+ *   mode 0: out2 = { sum (gt-rec)^2, max(gt) }  -> utils.psnr = 10 log10(max / (sum/count))
+ *                                                   (modules/utils.py:67-82: max(x), not max^2)
+ *   mode 1: out2 = { |rec>=thres & gt!=0|, |rec>=thres or gt!=0| }  -> IoU = out2[0] / out2[1]
+ *           (rec is NOT binarised in place, unlike get_I_and_U)               */
+int wire_eval_metric(void* stream, int mode, const float* rec, const float* gt,
+                     int64_t count, float thres, float* out2, float* partial);
+
 /* ---- layout helpers ---------------------------------------------------- */
 int wire_blocked_width(int K);   /* P = roundup(2K, 64) */
 int wire_c64_to_blocked(void* stream, const void* src, int64_t n, int K, float* dst);

@@ -514,6 +514,15 @@ extern "C" int wire_adam_step_flat(void* stream, float* param, const float* grad
   return WIRE_OK;
 }
 
+extern "C" int wire_eval_metric(void* stream, int mode, const float* rec, const float* gt, int64_t count,
+                                float thres, float* out2, float* partial) {
+  if ((mode != 0 && mode != 1) || count < 1 || !rec || !gt || !out2 || !partial)
+    return fail(WIRE_ERR_ARG, "bad argument to wire_eval_metric");
+  ProfScope ps((hipStream_t)stream, 3, 0);
+  HIPCHK(launch_metric((hipStream_t)stream, mode, rec, gt, count, thres, out2, partial));
+  return WIRE_OK;
+}
+
 // ---------------------------------------------------------------------------
 // layout helpers
 // ---------------------------------------------------------------------------

@@ -73,6 +73,10 @@ hipError_t launch_mse_grad(hipStream_t s, const float* y, const float* target, c
 hipError_t launch_adam(hipStream_t s, float* p, const float* g, float* m, float* v, int64_t count,
                        float step_size, float beta1, float beta2, float eps, float inv_sqrt_bc2);
 
+// ---- evaluation metrics: mode 0 -> {sum sq err, max gt}; mode 1 -> {intersection, union}
+hipError_t launch_metric(hipStream_t s, int mode, const float* rec, const float* gt, int64_t count, float thres,
+                         float* out, float* partial);
+
 // ---- 3M complex path: blocked-planar complex weight matrices + slab reduction
 hipError_t launch_pack3m(hipStream_t s, const float* W, const float* b, int K, int Kin, int Kp, int Kpin,
                          float* Wb_fwd, float* Wb_dg, float* bias);

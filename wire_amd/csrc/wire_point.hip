@@ -814,6 +814,72 @@ hipError_t launch_adam(hipStream_t s, float* p, const float* g, float* m, float*
 }
 
 // ===========================================================================
+// evaluation metrics on device (wire_image_denoise.py:161-178, wire_occupancy.py:160-162):
+//   mode 0: out = { sum (gt - rec)^2, max gt }            -> PSNR = 10 log10(max(x) / mse)
+//   mode 1: out = { |pred>=thres AND gt!=0|, |pred>=thres OR gt!=0| }   -> IoU
+// two-level deterministic reduction (block partials, then one block)
+// ===========================================================================
+#define MET_BLOCKS 1024
+__global__ __launch_bounds__(256) void metric_kernel(int mode, const float* __restrict__ rec,
+                                                     const float* __restrict__ gt, long long count,
+                                                     float thres, float* __restrict__ partial) {
+  __shared__ float r0[256], r1[256];
+  float a = 0.f, b = mode == 0 ? -3.4e38f : 0.f;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long long)gridDim.x * 256) {
+    const float x = gt[e], y = rec[e];
+    if (mode == 0) {
+      const float d = x - y;
+      a = __builtin_fmaf(d, d, a);
+      b = x > b ? x : b;
+    } else {
+      const bool p = y >= thres, q = x != 0.f;
+      a += (p && q) ? 1.f : 0.f;
+      b += (p || q) ? 1.f : 0.f;
+    }
+  }
+  r0[threadIdx.x] = a; r1[threadIdx.x] = b;
+  __syncthreads();
+  for (int sft = 128; sft >= 1; sft >>= 1) {
+    if (threadIdx.x < sft) {
+      r0[threadIdx.x] += r0[threadIdx.x + sft];
+      r1[threadIdx.x] = mode == 0 ? (r1[threadIdx.x] > r1[threadIdx.x + sft] ? r1[threadIdx.x] : r1[threadIdx.x + sft])
+                                  : r1[threadIdx.x] + r1[threadIdx.x + sft];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = r0[0]; partial[2 * blockIdx.x + 1] = r1[0]; }
+}
+__global__ void metric_final_kernel(int mode, const float* __restrict__ partial, int nb, float* __restrict__ out) {
+  __shared__ float r0[256], r1[256];
+  float a = 0.f, b = mode == 0 ? -3.4e38f : 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) {
+    a += partial[2 * i];
+    const float v = partial[2 * i + 1];
+    b = mode == 0 ? (v > b ? v : b) : b + v;
+  }
+  r0[threadIdx.x] = a; r1[threadIdx.x] = b;
+  __syncthreads();
+  for (int sft = 128; sft >= 1; sft >>= 1) {
+    if (threadIdx.x < sft) {
+      r0[threadIdx.x] += r0[threadIdx.x + sft];
+      r1[threadIdx.x] = mode == 0 ? (r1[threadIdx.x] > r1[threadIdx.x + sft] ? r1[threadIdx.x] : r1[threadIdx.x + sft])
+                                  : r1[threadIdx.x] + r1[threadIdx.x + sft];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = r0[0]; out[1] = r1[0]; }
+}
+hipError_t launch_metric(hipStream_t s, int mode, const float* rec, const float* gt, int64_t count, float thres,
+                         float* out, float* partial) {
+  if (count <= 0) return hipErrorInvalidValue;
+  unsigned nb = cdiv(count, 256);
+  if (nb > MET_BLOCKS) nb = MET_BLOCKS;
+  hipLaunchKernelGGL(metric_kernel, dim3(nb), dim3(256), 0, s, mode, rec, gt, (long long)count, thres, partial);
+  hipLaunchKernelGGL(metric_final_kernel, dim3(1), dim3(256), 0, s, mode, partial, (int)nb, out);
+  return hipGetLastError();
+}
+
+// ===========================================================================
 // 3M complex path (wire_gemm3m.hip): weights as blocked-planar complex matrices
 //   Wb_fwd[o][(i,re|im)] = W[o][i]            (lin = z W^T)
 //   Wb_dg [i][(o,re|im)] = conj(W[o][i])      (g_z = g_lin conj(W))

@@ -186,6 +186,30 @@ class FusedTrainer:
     def flat_grad(self) -> torch.Tensor:
         return self.gbuf[0][:self.count]
 
+    # ------------------------------------------------------------------ metrics
+    def psnr(self, rec: torch.Tensor, gt: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """utils.psnr(gt, rec) = 10 log10(max(gt) / mse) (modules/utils.py:67-82) computed on the
+        device; returns a 0-dim device tensor (no host sync, no image copy)."""
+        out = self._metric(0, rec, self.target if gt is None else gt, 0.0)
+        return 10.0 * torch.log10(out[1] / (out[0] / rec.numel()))
+
+    def iou(self, pred: torch.Tensor, gt: Optional[torch.Tensor] = None, thres: float = 0.5) -> torch.Tensor:
+        """volutils.get_IoU(pred, gt, thres) (modules/volutils.py:74-91) on the device; ``pred`` is
+        left untouched (the reference binarises it in place)."""
+        out = self._metric(1, pred, self.target if gt is None else gt, thres)
+        return out[0] / out[1]
+
+    def _metric(self, mode: int, rec: torch.Tensor, gt: torch.Tensor, thres: float) -> torch.Tensor:
+        rec = rec.detach().to(torch.float32).contiguous()
+        gt = gt.detach().to(self.dev, torch.float32).contiguous()
+        if rec.numel() != gt.numel():
+            raise ValueError("metric operands differ in size")
+        out = torch.empty(2, dtype=torch.float32, device=self.dev)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        _lib.check(self.L.wire_eval_metric(stream, mode, rec.data_ptr(), gt.data_ptr(), rec.numel(), thres,
+                                           out.data_ptr(), self.partial.data_ptr()), "metric")
+        return out
+
     # ------------------------------------------------------------------ inference
     @torch.no_grad()
     def render(self, first: int = 0, count: Optional[int] = None, tile: int = 1 << 20) -> torch.Tensor:
