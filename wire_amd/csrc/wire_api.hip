@@ -216,10 +216,10 @@ ScratchLayout scratch_layout(const Plan& p, int64_t n) {
     s.slab = off; off += (int64_t)s.S * p.Pl * pn;
     s.bslab = off; off += (int64_t)s.S * p.Pl;
   }
-  const int nbf = final_bwd_blocks(n);
+  const int nbf = final_bwd_blocks(n) + 32;            // + pre-reduction scratch
   s.fpw = off; off += (int64_t)nbf * p.O * p.P;
   s.fpb = off; off += (int64_t)nbf * p.O + 64;
-  s.crp = off; off += (int64_t)colreduce_blocks(n) * (p.cplx ? p.ldu : p.P) * 5;
+  s.crp = off; off += (int64_t)(colreduce_blocks(n) + 32) * (p.cplx ? p.ldu : p.P) * 5;
   s.total = off;
   return s;
 }

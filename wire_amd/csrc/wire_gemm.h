@@ -34,6 +34,7 @@ struct GemmEpiParams {
   const float* b0b = nullptr;
   int D = 0;
   int ldu = 0;
+  int wide = 0;                  // set by the launcher when 32-bit byte offsets could overflow
 #ifdef WIRE_ABLATE
   int ablate = 0;                // tools/gemm_tune only: 1 no global loads, 2 no LDS writes, 4 no barrier
 #endif

@@ -17,9 +17,12 @@
 //      are summed deterministically by reduce kernels in wire_point.hip).
 //
 // Tiling (both): 128x128 output tile per 256-thread workgroup, 4 waves, each
-// wave a 64x64 (or 32x128) block of v_mfma_f32_32x32x2_f32 tiles, BK = 32,
-// double-buffered LDS, two workgroups per CU so one workgroup's epilogue
-// (VALU transcendental work) overlaps the other's MFMA stream.
+// wave a 64x64 (or 32x128) block of v_mfma_f32_32x32x2_f32 tiles, BK = 16 (40 KB
+// of double-buffered LDS -> 4 workgroups per CU) or 32.
+//
+// These are the 4-multiplication (real-expanded) kernels: they serve the real
+// nets (siren / gauss / relu), wire2d, the per-layer API and complex_3m=0.  The
+// default path of `wire` layers is the 3-multiplication form in wire_gemm3m.hip.
 #include <cstdlib>
 #include <cstring>
 
@@ -31,16 +34,6 @@
 // BKT (K-slab per LDS stage) is a template parameter: 32 -> 72 KB LDS, 2 workgroups/CU;
 // 16 -> 40 KB LDS, 3 workgroups/CU.  LDS rows are padded by 4 floats (strides 36 / 20):
 // both make the 16-lane groups of ds_read_b128 hit 16 distinct 4-bank slots.
-
-// ---------------------------------------------------------------------------
-// epilogue bodies: one complex feature (re, im accumulators of the same lane)
-// ---------------------------------------------------------------------------
-template <int EPI>
-struct EpiTraits {
-  static constexpr bool complex_pair = (EPI == EPI_GABOR_FWD || EPI == EPI_GABOR_BWD ||
-                                        EPI == EPI_GABOR_BWD_FIRST);
-  static constexpr bool quad = (EPI == EPI_GABOR2D_FWD);
-};
 
 template <int EPI, int MT, int WN, int BKT>
 __global__ __launch_bounds__(256, (BKT == 32 ? 2 : 3)) void gemm_nt_kernel(

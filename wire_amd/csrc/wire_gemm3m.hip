@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 4) void gemm3m_nt_kernel(
   const int c_re = ((feat >> 5) << 6) + (feat & 31);
   const int c_im = c_re + 32;
   // fast path: every row of the tile exists and every feature of the wave is a real one
-  const bool full = (m_base + T3M <= M) && (f_w + 32 <= ep.kvalid);
+  const bool full = (m_base + T3M <= M) && (f_w + 32 <= ep.kvalid) && !ep.wide;
 
   if constexpr (EPI == EPI_STORE) {
 #pragma unroll
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 4) void gemm3m_nt_kernel(
     }
   } else if constexpr (EPI == EPI_GABOR_BWD) {
     const float m2s2 = -2.f * ep.scale * ep.scale;
-    if (m_base + T3M <= M) {
+    if (m_base + T3M <= M && !ep.wide) {
       const char* __restrict__ lin_b = reinterpret_cast<const char*>(ep.i0);
       const char* __restrict__ out_b = reinterpret_cast<const char*>(ep.i1);
       char* __restrict__ gl_b = reinterpret_cast<char*>(ep.o0);
@@ -303,14 +303,16 @@ hipError_t launch_gemm3m_nt(hipStream_t s, int epi, const float* A, int lda, con
                             int64_t M, int Kp_out, int Kp_in, const GemmEpiParams& ep) {
   if (M <= 0) return hipSuccess;
   if ((Kp_out & 31) || (Kp_in & 31) || (lda & 3) || (ldb & 3) || M > 0x7fffff00LL) return hipErrorInvalidValue;
-  // the fast epilogues share one row offset between their buffers and use 32-bit byte offsets
-  if ((epi == EPI_GABOR_FWD || epi == EPI_GABOR_BWD) && ep.ld0 != ep.ld1) return hipErrorInvalidValue;
-  if ((double)M * (double)(ep.ld1 > ep.ld0 ? ep.ld1 : ep.ld0) * 4.0 >= 4294967296.0) return hipErrorInvalidValue;
+  // the fast epilogues share one row offset between their buffers and use 32-bit byte offsets;
+  // anything else (different leading dims, buffers of 4 GB and more) takes the 64-bit path
+  GemmEpiParams e2 = ep;
+  if ((epi == EPI_GABOR_FWD || epi == EPI_GABOR_BWD) && ep.ld0 != ep.ld1) e2.wide = 1;
+  if ((double)M * (double)(ep.ld1 > ep.ld0 ? ep.ld1 : ep.ld0) * 4.0 >= 4294967296.0) e2.wide = 1;
   switch (epi) {
-    case EPI_STORE: return launch3m_t<EPI_STORE>(s, A, lda, B, ldb, M, Kp_out, Kp_in, ep);
-    case EPI_GABOR_FWD: return launch3m_t<EPI_GABOR_FWD>(s, A, lda, B, ldb, M, Kp_out, Kp_in, ep);
-    case EPI_GABOR_BWD: return launch3m_t<EPI_GABOR_BWD>(s, A, lda, B, ldb, M, Kp_out, Kp_in, ep);
-    case EPI_GABOR_BWD_FIRST: return launch3m_t<EPI_GABOR_BWD_FIRST>(s, A, lda, B, ldb, M, Kp_out, Kp_in, ep);
+    case EPI_STORE: return launch3m_t<EPI_STORE>(s, A, lda, B, ldb, M, Kp_out, Kp_in, e2);
+    case EPI_GABOR_FWD: return launch3m_t<EPI_GABOR_FWD>(s, A, lda, B, ldb, M, Kp_out, Kp_in, e2);
+    case EPI_GABOR_BWD: return launch3m_t<EPI_GABOR_BWD>(s, A, lda, B, ldb, M, Kp_out, Kp_in, e2);
+    case EPI_GABOR_BWD_FIRST: return launch3m_t<EPI_GABOR_BWD_FIRST>(s, A, lda, B, ldb, M, Kp_out, Kp_in, e2);
     default: return hipErrorInvalidValue;
   }
 }

@@ -41,9 +41,9 @@ LayerWs layer_ws(int64_t n, int in, int out) {
   w.bias = take(w.Pout);
   w.slab = take((int64_t)w.S * w.Pout * w.Pin);
   w.bslab = take((int64_t)w.S * w.Pout);
-  w.fpw = take((int64_t)final_bwd_blocks(n) * 8 * Pmax);
-  w.fpb = take((int64_t)final_bwd_blocks(n) * 8);
-  w.crp = take((int64_t)colreduce_blocks(n) * (w.Pout / 2) * 5);
+  w.fpw = take((int64_t)(final_bwd_blocks(n) + 32) * 8 * Pmax);
+  w.fpb = take((int64_t)(final_bwd_blocks(n) + 32) * 8);
+  w.crp = take((int64_t)(colreduce_blocks(n) + 32) * (w.Pout / 2) * 5);
   w.wf = take((int64_t)8 * Pmax);
   w.bfr = take(64);
   w.total = off;

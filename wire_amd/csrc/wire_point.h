@@ -31,7 +31,8 @@ hipError_t launch_final_bwd(hipStream_t s, int kind, int raw, const float* g_y, 
                             const float* wf, const float* lin, const float* out, int K, int P,
                             float omega, float scale, float* g_lin, float* part_w,
                             float* part_b);
-hipError_t launch_final_reduce(hipStream_t s, int kind, const float* part_w, const float* part_b,
+// part_w / part_b must have room for final_bwd_blocks(n) + 32 blocks (pre-reduction scratch)
+hipError_t launch_final_reduce(hipStream_t s, int kind, float* part_w, float* part_b,
                                int nblk, int O, int K, int P, float* gWf, float* gbf);
 
 // ---- weight-gradient slab reduction: slab[S][Pm][Pn] (+ bslab[S][Pm]) -> native grads
@@ -41,6 +42,7 @@ hipError_t launch_wgrad_reduce(hipStream_t s, int kind, const float* slab, const
 
 // ---- first-layer weight gradient: g_W0[c][d] = sum_n G[n][c] x[n][d], g_b0[c] = sum_n G[n][c]
 int colreduce_blocks(int64_t n);
+// partial must have room for (colreduce_blocks(n) + 32) * C * 5 floats
 hipError_t launch_colreduce(hipStream_t s, const float* G, int ldg, int C, const float* x, int D,
                             int64_t n, float* partial, float* gW0, float* gb0);
 

@@ -268,6 +268,7 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(
     const float m2s2 = -2.f * scale * scale;
     const int Pl = (KIND == NK_WIRE2D) ? 2 * P : P;
     const int lc = (KIND == NK_WIRE2D) ? (((f >> 5) << 7) + (f & 31)) : c0;
+#pragma unroll 4
     for (int r = 0; r < nr; ++r) {
       const long long row = r0 + r;
       float gr = 0.f, gi = 0.f;
@@ -357,6 +358,37 @@ hipError_t launch_final_bwd(hipStream_t s, int kind, int raw, const float* g_y, 
   return hipGetLastError();
 }
 
+// pre-reduction of per-row-block partials: in[nblk][C] -> out[nchunk][C], chunk c sums blocks
+// [c*per, (c+1)*per).  Keeps the final reductions short (they were latency-bound over 1024 blocks).
+#define PRE_CHUNKS 32
+__global__ __launch_bounds__(256) void prereduce_kernel(const float* __restrict__ in, int nblk, int C, int per,
+                                                        float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int ch = blockIdx.y;
+  if (c >= C) return;
+  const int b0 = ch * per;
+  int b1 = b0 + per;
+  if (b1 > nblk) b1 = nblk;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int b = b0;
+  for (; b + 3 < b1; b += 4) {
+    a0 += in[(size_t)b * C + c];
+    a1 += in[(size_t)(b + 1) * C + c];
+    a2 += in[(size_t)(b + 2) * C + c];
+    a3 += in[(size_t)(b + 3) * C + c];
+  }
+  for (; b < b1; ++b) a0 += in[(size_t)b * C + c];
+  out[(size_t)ch * C + c] = (a0 + a1) + (a2 + a3);
+}
+// returns the number of blocks left (nblk itself when no pre-reduction was worth it)
+static int prereduce(hipStream_t s, const float* in, int nblk, int C, float* out) {
+  if (nblk <= 2 * PRE_CHUNKS) return nblk;
+  const int per = (nblk + PRE_CHUNKS - 1) / PRE_CHUNKS;
+  const int nch = (nblk + per - 1) / per;
+  hipLaunchKernelGGL(prereduce_kernel, dim3(cdiv(C, 256), (unsigned)nch), dim3(256), 0, s, in, nblk, C, per, out);
+  return nch;
+}
+
 // g_Wf = g_y^T conj(z):  re = sum g z_re, im = -sum g z_im;  g_bf = sum g + 0j
 // block = 64 columns x 4 partial groups (each group strides over the row blocks), LDS combine
 __global__ __launch_bounds__(256) void final_reduce_kernel(int kind, const float* __restrict__ part_w,
@@ -396,11 +428,16 @@ __global__ __launch_bounds__(256) void final_reduce_kernel(int kind, const float
   }
 }
 
-hipError_t launch_final_reduce(hipStream_t s, int kind, const float* part_w, const float* part_b,
+hipError_t launch_final_reduce(hipStream_t s, int kind, float* part_w, float* part_b,
                                int nblk, int O, int K, int P, float* gWf, float* gbf) {
+  // the partial buffers have room for nblk + PRE_CHUNKS blocks (final_bwd_blocks adds the slack)
+  float* w2 = part_w + (size_t)nblk * O * P;
+  float* b2 = part_b + (size_t)nblk * O;
+  const int nw = prereduce(s, part_w, nblk, O * P, w2);
+  const int nb = prereduce(s, part_b, nblk, O, b2);
   dim3 grid(cdiv(K, 64), (unsigned)O);
-  hipLaunchKernelGGL(final_reduce_kernel, grid, dim3(256), 0, s, kind, part_w, part_b, nblk, O, K, P,
-                     gWf, gbf);
+  hipLaunchKernelGGL(final_reduce_kernel, grid, dim3(256), 0, s, kind, nw == nblk ? part_w : w2,
+                     nb == nblk ? part_b : b2, nw == nblk ? nblk : nw, O, K, P, gWf, gbf);
   return hipGetLastError();
 }
 
@@ -558,8 +595,10 @@ hipError_t launch_colreduce(hipStream_t s, const float* G, int ldg, int C, const
   const int nblk = colreduce_blocks(n);
   dim3 grid((unsigned)nblk, cdiv(C, 256));
   hipLaunchKernelGGL(colreduce_kernel, grid, dim3(256), 0, s, G, ldg, C, x, D, (long long)n, partial);
-  hipLaunchKernelGGL(colreduce_final_kernel, dim3(cdiv(C, 64)), dim3(256), 0, s, partial, nblk, C, D,
-                     gW0, gb0);
+  float* p2 = partial + (size_t)nblk * C * 5;            // slack reserved by colreduce_partial_floats
+  const int nb = prereduce(s, partial, nblk, C * 5, p2);
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3(cdiv(C, 64)), dim3(256), 0, s, nb == nblk ? partial : p2, nb,
+                     C, D, gW0, gb0);
   return hipGetLastError();
 }
 
@@ -913,24 +952,32 @@ hipError_t launch_pack3m(hipStream_t s, const float* W, const float* b, int K, i
 }
 
 // g_W.re = P1 + P2, g_W.im = P3 - P1 + P2 summed over the row splits; g_b from the column sums
-__global__ void wgrad3m_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab, int S,
-                                      int K, int Kin, int Kp_o, int Kp_i, float* __restrict__ gW,
-                                      float* __restrict__ gb) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void wgrad3m_reduce_kernel(const float* __restrict__ slab,
+                                      const float* __restrict__ bslab, int S, int K, int Kin, int Kp_o,
+                                      int Kp_i, float* __restrict__ gW, float* __restrict__ gb) {
+  // block = 64 input features x 4 groups of row splits; partial sums combined through LDS
+  __shared__ float red[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + tx;
   const int o = blockIdx.y;
   const size_t plane = (size_t)Kp_o * Kp_i;
+  float sr = 0.f, si = 0.f;
   if (i < Kin) {
-    float sr = 0.f, si = 0.f;
-    for (int s = 0; s < S; ++s) {
+    for (int s = ty; s < S; s += 4) {
       const float* p = slab + (size_t)s * 3 * plane + (size_t)o * Kp_i + i;
       const float p1 = p[0], p2 = p[plane], p3 = p[2 * plane];
       sr += p1 + p2;
       si += (p3 - p1) + p2;
     }
-    gW[((size_t)o * Kin + i) * 2] = sr;
-    gW[((size_t)o * Kin + i) * 2 + 1] = si;
   }
-  if (i == 0) {
+  red[0][ty][tx] = sr;
+  red[1][ty][tx] = si;
+  __syncthreads();
+  if (ty == 0 && i < Kin) {
+    gW[((size_t)o * Kin + i) * 2] = (red[0][0][tx] + red[0][1][tx]) + (red[0][2][tx] + red[0][3][tx]);
+    gW[((size_t)o * Kin + i) * 2 + 1] = (red[1][0][tx] + red[1][1][tx]) + (red[1][2][tx] + red[1][3][tx]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     float br = 0.f, bi = 0.f;
     for (int s = 0; s < S; ++s) {
       br += bslab[((size_t)s * 2 + 0) * Kp_o + o];
@@ -943,6 +990,6 @@ __global__ void wgrad3m_reduce_kernel(const float* __restrict__ slab, const floa
 hipError_t launch_wgrad3m_reduce(hipStream_t s, const float* slab, const float* bslab, int S, int K, int Kin,
                                  int Kp_o, int Kp_i, float* gW, float* gb) {
   dim3 grid(cdiv(Kin, 64), (unsigned)K);
-  hipLaunchKernelGGL(wgrad3m_reduce_kernel, grid, dim3(64), 0, s, slab, bslab, S, K, Kin, Kp_o, Kp_i, gW, gb);
+  hipLaunchKernelGGL(wgrad3m_reduce_kernel, grid, dim3(256), 0, s, slab, bslab, S, K, Kin, Kp_o, Kp_i, gW, gb);
   return hipGetLastError();
 }
