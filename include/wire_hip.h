@@ -135,6 +135,19 @@ int wire_final_bwd(void* stream, const float* g_y, const void* z,
                    int out_features, void* g_z, void* g_Wf, void* g_bf,
                    void* ws, int64_t ws_bytes);
 
+/* SineLayer / GaussLayer / ReLULayer .forward (modules/siren.py:48-49,
+ * gauss.py:27-28, relu.py:28-29) and their backward on native f32 tensors:
+ * x [n][in], W [out][in], b [out] -> act [n][out].  kind = WIRE_KIND_SIREN /
+ * _GAUSS / _RELU; ws as for wire_gabor_fwd.                                   */
+int wire_real_layer_fwd(void* stream, int kind, const float* x, const float* W,
+                        const float* b, float omega0, float scale0, int64_t n,
+                        int in_features, int out_features, float* act_out,
+                        void* ws, int64_t ws_bytes);
+int wire_real_layer_bwd(void* stream, int kind, const float* g_act, const float* x,
+                        const float* W, const float* b, float omega0, float scale0,
+                        int64_t n, int in_features, int out_features, float* g_x,
+                        float* g_W, float* g_b, void* ws, int64_t ws_bytes);
+
 /* ---- training-step glue (wire_image_denoise.py:142-157,
  *      wire_occupancy.py:137-158) ---------------------------------------- */
 /* coords[r] = grid point of flat index idx[r] (idx NULL -> first + r).

@@ -445,3 +445,36 @@ def test_device_psnr_matches_reference_known_answer():
     tr = FusedTrainer(model, (H, W), torch.tensor(x.reshape(-1, 3)))
     val = float(tr.psnr(torch.tensor(xh.reshape(-1, 3), device=DEV)).item())
     assert abs(val - float(misc["psnr_val"])) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["small_siren", "small_gauss", "small_relu"])
+def test_real_layers_identical_inputs_and_backward(name):
+    """SineLayer / GaussLayer / ReLULayer .forward (per-layer API used by
+    modules/utils.py:246-252) on the reference's own layer inputs, and one layer's backward."""
+    rec = load_golden(name)
+    model = load_small(rec, build_model(rec))
+    m = meta(rec)
+    x = torch.tensor(rec["coords"], device=DEV)
+    for i in range(m["L"] + 1):
+        out = model.net[i](x)
+        assert out.dtype == torch.float32
+        assert relmax(out.detach().cpu().numpy(), rec[f"act{i}"]) <= 1e-5, f"layer {i}"
+        x = torch.tensor(rec[f"act{i}"], device=DEV)
+    # backward of hidden layer 1 on the reference's act0
+    kind = m["kind"]
+    z = torch.tensor(rec["act0"], device=DEV, requires_grad=True)
+    out = model.net[1](z)
+    rng = np.random.default_rng(1)
+    g = rng.standard_normal(tuple(out.shape)).astype(np.float32)
+    model.zero_grad()
+    out.backward(torch.tensor(g, device=DEV))
+    torch.cuda.synchronize()
+    W = rec["p:net.1.linear.weight"].astype(np.float64)
+    b = rec["p:net.1.linear.bias"].astype(np.float64)
+    z64 = rec["act0"].astype(np.float64).reshape(-1, W.shape[1])
+    lin = z64 @ W.T + b
+    o = wo.real_act(kind, lin, m["om"], m["sc"])
+    gl = wo.real_act_grad(kind, g.reshape(lin.shape).astype(np.float64), lin, o, m["om"], m["sc"])
+    assert relmax(z.grad.cpu().numpy().reshape(lin.shape[0], -1), gl @ W) < 2e-5
+    assert relmax(model.net[1].linear.weight.grad.cpu().numpy(), gl.T @ z64) < 2e-5
+    assert relmax(model.net[1].linear.bias.grad.cpu().numpy(), gl.sum(0)) < 2e-5

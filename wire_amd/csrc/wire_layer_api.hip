@@ -174,3 +174,70 @@ extern "C" int wire_final_bwd(void* stream, const float* g_y, const void* z, con
   if (g_z) LCHK(launch_blocked_to_c64(s, W_ + w.gxb, n, in_features, w.Pin, (float*)g_z));
   return WIRE_OK;
 }
+
+// ---------------------------------------------------------------------------
+// real-valued layers: SineLayer / GaussLayer / ReLULayer .forward
+// (modules/siren.py:48-49, gauss.py:27-28, relu.py:28-29) on native [n][in] f32 tensors.
+// ---------------------------------------------------------------------------
+static int real_epi_fwd(int kind) {
+  return kind == WIRE_KIND_SIREN ? EPI_SIREN_FWD : kind == WIRE_KIND_GAUSS ? EPI_GAUSS_FWD : EPI_RELU_FWD;
+}
+static int real_forward_ws(hipStream_t s, const LayerWs& w, float* W_, int kind, const void* x, const void* Wt,
+                           const void* b, float omega0, float scale0, int64_t n, int in, int out, int Pin,
+                           int Pout) {
+  LCHK(launch_pad_rows(s, (const float*)x, n, in, Pin, W_ + w.xb));
+  LCHK(launch_pack_hidden(s, kind, (const float*)Wt, (const float*)b, nullptr, nullptr, out, in, Pout, Pin,
+                          W_ + w.btf, W_ + w.btd, W_ + w.bias));
+  GemmEpiParams ep;
+  ep.bias = W_ + w.bias; ep.o0 = W_ + w.lin; ep.o1 = W_ + w.out; ep.ld0 = Pout; ep.ld1 = Pout;
+  ep.omega = omega0; ep.scale = scale0; ep.kvalid = out;
+  LCHK(launch_gemm_nt(s, real_epi_fwd(kind), W_ + w.xb, Pin, W_ + w.btf, Pin, n, Pout, Pin, ep));
+  return WIRE_OK;
+}
+
+extern "C" int wire_real_layer_fwd(void* stream, int kind, const float* x, const float* W, const float* b,
+                                   float omega0, float scale0, int64_t n, int in_features, int out_features,
+                                   float* act_out, void* ws, int64_t ws_bytes) {
+  if (kind < WIRE_KIND_SIREN || kind > WIRE_KIND_RELU || n < 0 || in_features < 1 || out_features < 1 || !x ||
+      !W || !b || !act_out || !ws)
+    return wire_fail_(WIRE_ERR_ARG, "bad argument to wire_real_layer_fwd");
+  if (n == 0) return WIRE_OK;
+  const LayerWs w = layer_ws(n, in_features, out_features);   // complex sizing is an upper bound
+  if (ws_bytes < w.total * 4) return wire_fail_(WIRE_ERR_SIZE, "layer workspace too small");
+  const int Pin = rup(in_features, 64), Pout = rup(out_features, 64);
+  hipStream_t s = (hipStream_t)stream;
+  float* W_ = (float*)ws;
+  if (int rc = real_forward_ws(s, w, W_, kind, x, W, b, omega0, scale0, n, in_features, out_features, Pin, Pout))
+    return rc;
+  LCHK(launch_unpad_rows(s, W_ + w.out, n, out_features, Pout, act_out));
+  return WIRE_OK;
+}
+
+extern "C" int wire_real_layer_bwd(void* stream, int kind, const float* g_act, const float* x, const float* W,
+                                   const float* b, float omega0, float scale0, int64_t n, int in_features,
+                                   int out_features, float* g_x, float* g_W, float* g_b, void* ws,
+                                   int64_t ws_bytes) {
+  if (kind < WIRE_KIND_SIREN || kind > WIRE_KIND_RELU || n <= 0 || in_features < 1 || out_features < 1 ||
+      !g_act || !x || !W || !b || !g_W || !g_b || !ws)
+    return wire_fail_(WIRE_ERR_ARG, "bad argument to wire_real_layer_bwd");
+  const LayerWs w = layer_ws(n, in_features, out_features);
+  if (ws_bytes < w.total * 4) return wire_fail_(WIRE_ERR_SIZE, "layer workspace too small");
+  const int Pin = rup(in_features, 64), Pout = rup(out_features, 64);
+  hipStream_t s = (hipStream_t)stream;
+  float* W_ = (float*)ws;
+  if (int rc = real_forward_ws(s, w, W_, kind, x, W, b, omega0, scale0, n, in_features, out_features, Pin, Pout))
+    return rc;
+  LCHK(launch_pad_rows(s, g_act, n, out_features, Pout, W_ + w.gact));
+  LCHK(launch_real_act_bwd_point(s, kind, W_ + w.gact, W_ + w.lin, W_ + w.out, n, Pout, omega0, scale0,
+                                 W_ + w.glin));
+  if (g_x) {
+    GemmEpiParams ep; ep.o0 = W_ + w.gxb; ep.ld0 = Pin;
+    LCHK(launch_gemm_nt(s, EPI_STORE, W_ + w.glin, Pout, W_ + w.btd, Pout, n, Pin, Pout, ep));
+    LCHK(launch_unpad_rows(s, W_ + w.gxb, n, in_features, Pin, g_x));
+  }
+  const int S = gemm_tn_splits(n, Pout, Pin, w.S);
+  LCHK(launch_gemm_tn(s, W_ + w.glin, Pout, W_ + w.xb, Pin, n, Pout, Pin, S, W_ + w.slab, W_ + w.bslab));
+  LCHK(launch_wgrad_reduce(s, kind, W_ + w.slab, W_ + w.bslab, S, out_features, in_features, Pout, Pin, g_W,
+                           g_b, nullptr, nullptr));
+  return WIRE_OK;
+}

@@ -61,6 +61,10 @@ hipError_t launch_gabor_bwd_first_point(hipStream_t s, const float* g, const flo
                                         int64_t n, int K, int P, float omega, float scale, float* g_u,
                                         int ldu);
 
+hipError_t launch_real_act_bwd_point(hipStream_t s, int kind, const float* g, const float* lin,
+                                     const float* out, int64_t n, int P, float omega, float scale,
+                                     float* g_lin);
+
 // ---- positional encoding (modules/relu.py:62-75) into a [n][Pin] padded row
 hipError_t launch_posenc(hipStream_t s, const float* coords, int64_t n, int D, int F, int Pin,
                          float* dst);

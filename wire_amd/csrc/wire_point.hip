@@ -690,6 +690,29 @@ __global__ void gabor_bwd_first_point_kernel(const float* __restrict__ g, const 
     g_u[row * ldu + f] = gu;
   }
 }
+template <int ACT>
+__global__ void real_act_bwd_point_kernel(const float* __restrict__ g, const float* __restrict__ lin,
+                                          const float* __restrict__ out, long long n, int P, float omega,
+                                          float scale, float* __restrict__ g_lin) {
+  const long long row = blockIdx.x;
+  for (int c = threadIdx.x; c < P; c += blockDim.x) {
+    const size_t i = (size_t)row * P + c;
+    g_lin[i] = real_act_bwd<ACT>(g[i], lin[i], out[i], omega, scale);
+  }
+}
+hipError_t launch_real_act_bwd_point(hipStream_t s, int kind, const float* g, const float* lin,
+                                     const float* out, int64_t n, int P, float omega, float scale,
+                                     float* g_lin) {
+  if (n <= 0) return hipSuccess;
+  dim3 grid((unsigned)n), blk(256);
+  switch (kind) {
+    case NK_SIREN: hipLaunchKernelGGL(real_act_bwd_point_kernel<ACT_SIREN>, grid, blk, 0, s, g, lin, out, (long long)n, P, omega, scale, g_lin); break;
+    case NK_GAUSS: hipLaunchKernelGGL(real_act_bwd_point_kernel<ACT_GAUSS>, grid, blk, 0, s, g, lin, out, (long long)n, P, omega, scale, g_lin); break;
+    case NK_RELU: hipLaunchKernelGGL(real_act_bwd_point_kernel<ACT_RELU>, grid, blk, 0, s, g, lin, out, (long long)n, P, omega, scale, g_lin); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
 hipError_t launch_gabor_bwd_point(hipStream_t s, const float* g, const float* lin, const float* out,
                                   int64_t n, int P, float omega, float scale, float* g_lin) {
   if (n <= 0) return hipSuccess;

@@ -178,3 +178,49 @@ class _FinalLinearFunction(torch.autograd.Function):
 
 def final_linear_real(z, Wf, bf):
     return _FinalLinearFunction.apply(z, Wf, bf)
+
+
+class _RealLayerFunction(torch.autograd.Function):
+    """SineLayer / GaussLayer / ReLULayer on native tensors: wire_real_layer_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, kind: str, omega0: float, scale0: float):
+        L = _lib.lib()
+        _require_cuda(x, "layer input")
+        _require_cuda(W, "layer weight")
+        dev = x.device
+        out_f, in_f = W.shape
+        xin = x.detach().to(torch.float32).contiguous()
+        n = xin.numel() // in_f
+        Wn, bn = _native(W), _native(b)
+        ws_bytes = _lib.check(L.wire_layer_ws_bytes(n, in_f, out_f), "wire_layer_ws_bytes")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        act = torch.empty(tuple(x.shape[:-1]) + (out_f,), dtype=torch.float32, device=dev)
+        _lib.check(L.wire_real_layer_fwd(_stream_ptr(dev), _lib.KIND[kind], xin.data_ptr(), Wn.data_ptr(),
+                                         bn.data_ptr(), omega0, scale0, n, in_f, out_f, act.data_ptr(),
+                                         ws.data_ptr(), ws_bytes), "wire_real_layer_fwd")
+        ctx.save_for_backward(xin, Wn, bn)
+        ctx.cfg = (kind, omega0, scale0, n, in_f, out_f, tuple(x.shape), x.requires_grad)
+        return act
+
+    @staticmethod
+    def backward(ctx, g_act):
+        L = _lib.lib()
+        xin, Wn, bn = ctx.saved_tensors
+        kind, omega0, scale0, n, in_f, out_f, xshape, need_gx = ctx.cfg
+        dev = g_act.device
+        g = g_act.detach().to(torch.float32).contiguous()
+        ws_bytes = _lib.check(L.wire_layer_ws_bytes(n, in_f, out_f), "wire_layer_ws_bytes")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        gW = torch.empty_like(Wn)
+        gb = torch.empty_like(bn)
+        gx = torch.empty(xshape, dtype=torch.float32, device=dev) if need_gx else None
+        _lib.check(L.wire_real_layer_bwd(_stream_ptr(dev), _lib.KIND[kind], g.data_ptr(), xin.data_ptr(),
+                                         Wn.data_ptr(), bn.data_ptr(), omega0, scale0, n, in_f, out_f,
+                                         None if gx is None else gx.data_ptr(), gW.data_ptr(), gb.data_ptr(),
+                                         ws.data_ptr(), ws_bytes), "wire_real_layer_bwd")
+        return gx, gW, gb, None, None, None
+
+
+def real_layer(kind: str, x, W, b, omega0: float, scale0: float):
+    return _RealLayerFunction.apply(x, W, b, kind, float(omega0), float(scale0))

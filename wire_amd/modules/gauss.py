@@ -28,8 +28,9 @@ class GaussLayer(ActivationLayer):
         return [self.linear.weight, self._bias_or_zeros(self.linear)]
 
     def forward(self, input):
-        raise NotImplementedError("stand-alone GaussLayer.forward is not exposed by libwire_hip "
-                                  "ABI v1; call the INR (fused path)")
+        from .. import functional as Fh
+        return Fh.real_layer(self.kind, input, self.linear.weight, self._bias_or_zeros(self.linear),
+                             0.0, float(self.scale))
 
 
 class INR(HipINR):

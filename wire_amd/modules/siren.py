@@ -38,8 +38,9 @@ class SineLayer(ActivationLayer):
         return [self.linear.weight, self._bias_or_zeros(self.linear)]
 
     def forward(self, input):
-        raise NotImplementedError("stand-alone SineLayer.forward is not exposed by libwire_hip "
-                                  "ABI v1; call the INR (fused path)")
+        from .. import functional as Fh
+        return Fh.real_layer(self.kind, input, self.linear.weight, self._bias_or_zeros(self.linear),
+                             float(self.omega_0), 0.0)
 
 
 class INR(HipINR):
