@@ -162,8 +162,8 @@ def main():
     tr = FusedTrainer(model, (H, W), target, lr=5e-3, niters=2000, micro_shards=args.micro_shards)
 
     def one_step():
-        idx = torch.randperm(npts, device=dev)          # wire_image_denoise.py:142, on device
-        loss = tr.step(idx)
+        idx = tr.permutation()                          # torch.randperm per epoch (wire_image_denoise.py:142),
+        loss = tr.step(idx)                             # generated on a side stream under the previous step
         tr.scheduler_step()
         return loss
 

@@ -118,6 +118,27 @@ class FusedTrainer:
         self.gy = torch.empty(n * self.O, dtype=torch.float32, device=self.dev)
         self._cap = n
 
+    # ------------------------------------------------------------------ permutations
+    def permutation(self, n: Optional[int] = None) -> torch.Tensor:
+        """torch.randperm(n) for the next epoch (wire_image_denoise.py:142), generated on a side
+        stream while the current step computes: returns the permutation prepared by the previous
+        call (made visible to the compute stream) and starts the next one.  Same generator, same
+        sequence as calling torch.randperm(n, device=...) in a loop."""
+        n = self.npoints if n is None else int(n)
+        cur = torch.cuda.current_stream(self.dev)
+        if getattr(self, "_perm_stream", None) is None:
+            self._perm_stream = torch.cuda.Stream(device=self.dev)
+            self._perm_next = None
+        if self._perm_next is None or self._perm_next.numel() != n:
+            with torch.cuda.stream(self._perm_stream):
+                self._perm_next = torch.randperm(n, device=self.dev)
+        cur.wait_stream(self._perm_stream)
+        out = self._perm_next
+        out.record_stream(cur)
+        with torch.cuda.stream(self._perm_stream):
+            self._perm_next = torch.randperm(n, device=self.dev)
+        return out
+
     # ------------------------------------------------------------------ schedule
     def current_lr(self) -> float:
         """LambdaLR(lambda x: gamma**min(x/niters, 1)) (wire_image_denoise.py:128)."""
