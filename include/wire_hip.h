@@ -111,6 +111,22 @@ int wire_mlp_bwd(void* stream, const wire_net_desc* d, const float* packed,
                  void* scratch, int64_t scratch_bytes,
                  void* const* grads_host);
 
+/* One training step's compute in a single call (wire_image_denoise.py:148-156:
+ * model(b_coords) -> rec[b_indices] = pix -> mse -> backward): forward, MSE against
+ * target[idx[r]] (or target[first + r] when idx is NULL), loss_out[0] = weight *
+ * mean((y - t)^2), optional rec scatter, and every parameter gradient of
+ * weight * loss into grads_host (overwritten).  For `wire` with O <= 4 the final
+ * linear forward, the loss, its gradient, the final linear backward and the last
+ * layer's Gabor gradient are ONE kernel (a single pass over out_L / lin_L); other
+ * kinds run wire_mlp_fwd + wire_mse_grad + wire_mlp_bwd internally.
+ * y [n][O] and g_y [n][O] are outputs; partial >= 4096 floats.                 */
+int wire_train_fwd_bwd(void* stream, const wire_net_desc* d, const float* packed,
+                       const float* coords, int64_t n, const float* target,
+                       const int64_t* idx, int64_t first, float weight, float* y,
+                       float* g_y, float* loss_out, float* rec, float* partial,
+                       void* act, int64_t act_bytes, void* scratch,
+                       int64_t scratch_bytes, void* const* grads_host);
+
 /* ---- per-layer path (ComplexGaborLayer.forward, modules/wire.py:88-93) -- */
 /* x: [n][in] f32 when is_first else [n][in] c64; W: [out][in] f32/c64;
  * act_out [n][out] c64 (interleaved); lin_out (optional, may be NULL) has the

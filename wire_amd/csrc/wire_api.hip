@@ -310,13 +310,11 @@ extern "C" int wire_pack_params(void* stream, const wire_net_desc* d, const void
 // ---------------------------------------------------------------------------
 // whole-network forward
 // ---------------------------------------------------------------------------
-extern "C" int wire_mlp_fwd(void* stream, const wire_net_desc* d, const float* packed,
-                            const float* coords, int64_t n, float* y, void* act, int64_t act_bytes,
-                            int save_for_bwd) {
-  Plan p; if (int rc = make_plan(d, p)) return rc;
+static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const float* coords, int64_t n,
+                        float* y, void* act, int64_t act_bytes, int save_for_bwd, bool do_final) {
   if (n < 0) return fail(WIRE_ERR_ARG, "negative n");
   if (n == 0) return WIRE_OK;
-  if (!packed || !coords || !y || !act) return fail(WIRE_ERR_ARG, "null pointer");
+  if (!packed || !coords || (do_final && !y) || !act) return fail(WIRE_ERR_ARG, "null pointer");
   const ActLayout a = act_layout(p, n, save_for_bwd);
   if (act_bytes < a.total * 4) return fail(WIRE_ERR_SIZE, "act buffer %lld < %lld bytes",
                                            (long long)act_bytes, (long long)a.total * 4);
@@ -358,21 +356,30 @@ extern "C" int wire_mlp_fwd(void* stream, const wire_net_desc* d, const float* p
       HIPCHK(launch_gemm_nt(s, epi_fwd(p.kind), out_l(l - 1), p.P, packed + p.off_fwd[l], p.P, n,
                             p.Pl, p.P, ep));
   }
-  { ProfScope ps(s, 3, 0);
-    HIPCHK(launch_final_fwd(s, out_l(p.L), n, p.P, p.O, packed + p.off_wf, packed + p.off_bf, y)); }
+  if (do_final) {
+    ProfScope ps(s, 3, 0);
+    HIPCHK(launch_final_fwd(s, out_l(p.L), n, p.P, p.O, packed + p.off_wf, packed + p.off_bf, y));
+  }
   return WIRE_OK;
+}
+
+extern "C" int wire_mlp_fwd(void* stream, const wire_net_desc* d, const float* packed,
+                            const float* coords, int64_t n, float* y, void* act, int64_t act_bytes,
+                            int save_for_bwd) {
+  Plan p; if (int rc = make_plan(d, p)) return rc;
+  return mlp_fwd_core(stream, p, packed, coords, n, y, act, act_bytes, save_for_bwd, true);
 }
 
 // ---------------------------------------------------------------------------
 // whole-network backward
 // ---------------------------------------------------------------------------
-extern "C" int wire_mlp_bwd(void* stream, const wire_net_desc* d, const float* packed,
-                            const float* coords, int64_t n, const float* g_y, const void* act,
-                            int64_t act_bytes, void* scratch, int64_t scratch_bytes,
-                            void* const* grads) {
-  Plan p; if (int rc = make_plan(d, p)) return rc;
+// do_final = false: the caller (wire_train_fwd_bwd) has already run the fused final stage, i.e.
+// g_lin of layer L is in the scratch's first gradient buffer and the final-layer partials are there.
+static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const float* coords, int64_t n,
+                        const float* g_y, const void* act, int64_t act_bytes, void* scratch,
+                        int64_t scratch_bytes, void* const* grads, bool do_final) {
   if (n <= 0) return fail(WIRE_ERR_ARG, "backward needs n > 0");
-  if (!packed || !coords || !g_y || !act || !scratch || !grads) return fail(WIRE_ERR_ARG, "null pointer");
+  if (!packed || !coords || (do_final && !g_y) || !act || !scratch || !grads) return fail(WIRE_ERR_ARG, "null pointer");
   for (int i = 0; i < p.ntens; ++i) if (!grads[i]) return fail(WIRE_ERR_ARG, "grads[%d] is null", i);
   const ActLayout a = act_layout(p, n, 1);
   const ScratchLayout sc = scratch_layout(p, n);
@@ -389,7 +396,11 @@ extern "C" int wire_mlp_bwd(void* stream, const wire_net_desc* d, const float* p
 
   // ---- final linear + activation gradient of layer L
   const int nbf = final_bwd_blocks(n);
-  {
+  if (!do_final) {
+    ProfScope ps(s, 3, 0);
+    HIPCHK(launch_final_reduce(s, p.kind, Sx + sc.fpw, Sx + sc.fpb, nbf, p.O, p.K, p.P,
+                               (float*)grads[p.ntens - 2], (float*)grads[p.ntens - 1]));
+  } else {
     ProfScope ps(s, 3, 0);
     const float wL = (p.L == 0) ? p.w1 : p.w;
     if (p.L == 0 && p.cplx) {
@@ -477,6 +488,50 @@ extern "C" int wire_mlp_bwd(void* stream, const wire_net_desc* d, const float* p
                                (float*)grads[0], (float*)grads[1], nullptr, nullptr));
   }
   return WIRE_OK;
+}
+
+extern "C" int wire_mlp_bwd(void* stream, const wire_net_desc* d, const float* packed,
+                            const float* coords, int64_t n, const float* g_y, const void* act,
+                            int64_t act_bytes, void* scratch, int64_t scratch_bytes,
+                            void* const* grads) {
+  Plan p; if (int rc = make_plan(d, p)) return rc;
+  return mlp_bwd_core(stream, p, packed, coords, n, g_y, act, act_bytes, scratch, scratch_bytes, grads, true);
+}
+
+// ---------------------------------------------------------------------------
+// fused training core: forward -> MSE -> backward in one call
+// ---------------------------------------------------------------------------
+extern "C" int wire_train_fwd_bwd(void* stream, const wire_net_desc* d, const float* packed,
+                                  const float* coords, int64_t n, const float* target, const int64_t* idx,
+                                  int64_t first, float weight, float* y, float* g_y, float* loss_out,
+                                  float* rec, float* partial, void* act, int64_t act_bytes, void* scratch,
+                                  int64_t scratch_bytes, void* const* grads) {
+  Plan p; if (int rc = make_plan(d, p)) return rc;
+  if (n <= 0) return fail(WIRE_ERR_ARG, "wire_train_fwd_bwd needs n > 0");
+  if (!target || !y || !g_y || !loss_out || !partial) return fail(WIRE_ERR_ARG, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const bool fuse = (p.kind == WIRE_KIND_WIRE) && p.L >= 1 && p.O <= 4 && final_fused_supported(p.P);
+  if (!fuse) {
+    if (int rc = mlp_fwd_core(stream, p, packed, coords, n, y, act, act_bytes, 1, true)) return rc;
+    { ProfScope ps(s, 3, 0);
+      HIPCHK(launch_mse_grad(s, y, target, idx, first, n, p.O, weight, g_y, loss_out, rec, partial)); }
+    return mlp_bwd_core(stream, p, packed, coords, n, g_y, act, act_bytes, scratch, scratch_bytes, grads, true);
+  }
+  if (int rc = mlp_fwd_core(stream, p, packed, coords, n, nullptr, act, act_bytes, 1, false)) return rc;
+  const ActLayout a = act_layout(p, n, 1);
+  const ScratchLayout sc = scratch_layout(p, n);
+  if (scratch_bytes < sc.total * 4) return fail(WIRE_ERR_SIZE, "scratch too small");
+  const float* A = (const float*)act;
+  float* Sx = (float*)scratch;
+  {
+    // final linear forward + MSE (loss, rec) + final linear backward + Gabor gradient of layer L:
+    // one pass over out_L / lin_L instead of three
+    ProfScope ps(s, 3, 0);
+    HIPCHK(launch_final_fused(s, A + a.out0 + (int64_t)p.L * n * p.P, A + a.lin1 + (int64_t)(p.L - 1) * n * p.Pl,
+                              n, p.P, p.O, packed + p.off_wf, packed + p.off_bf, target, idx, first, weight,
+                              p.w, p.s, y, rec, Sx + sc.ga, Sx + sc.fpw, Sx + sc.fpb, Sx + sc.crp, loss_out));
+  }
+  return mlp_bwd_core(stream, p, packed, coords, n, nullptr, act, act_bytes, scratch, scratch_bytes, grads, false);
 }
 
 // ---------------------------------------------------------------------------

@@ -35,6 +35,16 @@ hipError_t launch_final_bwd(hipStream_t s, int kind, int raw, const float* g_y, 
 hipError_t launch_final_reduce(hipStream_t s, int kind, float* part_w, float* part_b,
                                int nblk, int O, int K, int P, float* gWf, float* gbf);
 
+// ---- fused final stage of a training step (wire, O <= 4): y = Re(z Wf^T + bf), MSE loss + dL/dy,
+// rec scatter, g_out = g_y conj(Wf), Gabor gradient of layer L, and the per-block partials of g_Wf /
+// g_bf in the SAME layout launch_final_bwd produces (FB_ROWS rows per block) for launch_final_reduce.
+bool final_fused_supported(int P);
+hipError_t launch_final_fused(hipStream_t s, const float* out, const float* lin, int64_t n, int P, int O,
+                              const float* wf, const float* bfr, const float* target, const int64_t* idx,
+                              int64_t first, float weight, float omega, float scale, float* y, float* rec,
+                              float* g_lin, float* part_w, float* part_b, float* loss_partial,
+                              float* loss_out);
+
 // ---- weight-gradient slab reduction: slab[S][Pm][Pn] (+ bslab[S][Pm]) -> native grads
 hipError_t launch_wgrad_reduce(hipStream_t s, int kind, const float* slab, const float* bslab,
                                int S, int K, int Kin, int Pm, int Pn, float* gW, float* gb,

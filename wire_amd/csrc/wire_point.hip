@@ -358,6 +358,183 @@ hipError_t launch_final_bwd(hipStream_t s, int kind, int raw, const float* g_y, 
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// fused final stage (training path, wire): one wave per row.
+// lane l owns features f = 32 g + 4 (l & 7) + j, j = 0..3, of group g = (l >> 3) + 8 pass: its row
+// slice is two float4 (re, im).  y_o is a butterfly over the wave; everything after it (loss term,
+// dL/dy, g_out, Gabor gradient, g_Wf partials) stays in registers.
+// ---------------------------------------------------------------------------
+#define FF_MAXO 4
+#define FF_MAXPASS 2      // P <= 1024 floats per row
+__global__ void mse_final_kernel(const float* __restrict__ partial, int nb, float lscale,
+                                 float* __restrict__ loss_out);
+bool final_fused_supported(int P) { return (P % 64) == 0 && P <= 512 * FF_MAXPASS; }
+
+template <int NPASS>
+__global__ __launch_bounds__(256) void final_fused_kernel(
+    const float* __restrict__ out, const float* __restrict__ lin, long long n, int P, int O,
+    const float* __restrict__ wf, const float* __restrict__ bfr, const float* __restrict__ target,
+    const int64_t* __restrict__ idx, long long first, float gscale, float omega, float scale,
+    float* __restrict__ y, float* __restrict__ rec, float* __restrict__ g_lin, float* __restrict__ part_w,
+    float* __restrict__ part_b, float* __restrict__ loss_partial) {
+  extern __shared__ float sm[];                        // [4 waves][O][P] g_wf partials + [4][O+1]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ngrp = P >> 6;
+  const long long r0 = (long long)blockIdx.x * FB_ROWS;
+  long long r1 = r0 + FB_ROWS;
+  if (r1 > n) r1 = n;
+  const float m2s2 = -2.f * scale * scale;
+
+  // this lane's columns and weights
+  int col[NPASS];
+  bool live[NPASS];
+  f32x4 wre[NPASS][FF_MAXO], wim[NPASS][FF_MAXO];
+  f32x4 are[NPASS][FF_MAXO], aim[NPASS][FF_MAXO];
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int g = (lane >> 3) + 8 * ps;
+    live[ps] = g < ngrp;
+    col[ps] = (g << 6) + 4 * (lane & 7);
+#pragma unroll
+    for (int o = 0; o < FF_MAXO; ++o) {
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      wre[ps][o] = z4; wim[ps][o] = z4; are[ps][o] = z4; aim[ps][o] = z4;
+      if (live[ps] && o < O) {
+        wre[ps][o] = *reinterpret_cast<const f32x4*>(wf + (size_t)o * P + col[ps]);
+        wim[ps][o] = *reinterpret_cast<const f32x4*>(wf + (size_t)o * P + col[ps] + 32);
+      }
+    }
+  }
+  float bsum[FF_MAXO] = {0.f, 0.f, 0.f, 0.f};
+  float lsum = 0.f;
+
+  for (long long row = r0 + wave; row < r1; row += 4) {
+    f32x4 zr[NPASS], zi[NPASS], lr[NPASS], li[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      zr[ps] = z4; zi[ps] = z4; lr[ps] = z4; li[ps] = z4;
+      if (live[ps]) {
+        const size_t o_ = (size_t)row * P + col[ps];
+        zr[ps] = *reinterpret_cast<const f32x4*>(out + o_);
+        zi[ps] = *reinterpret_cast<const f32x4*>(out + o_ + 32);
+        lr[ps] = *reinterpret_cast<const f32x4*>(lin + o_);
+        li[ps] = *reinterpret_cast<const f32x4*>(lin + o_ + 32);
+      }
+    }
+    float yo[FF_MAXO];
+#pragma unroll
+    for (int o = 0; o < FF_MAXO; ++o) {
+      float acc = 0.f;
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc = __builtin_fmaf(zr[ps][j], wre[ps][o][j], __builtin_fmaf(zi[ps][j], wim[ps][o][j], acc));
+      yo[o] = acc;
+    }
+#pragma unroll
+    for (int o = 0; o < FF_MAXO; ++o)
+      if (o < O) {
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) yo[o] += __shfl_xor(yo[o], sft);
+      }
+    const long long src = idx ? idx[row] : first + row;
+    float gy[FF_MAXO];
+#pragma unroll
+    for (int o = 0; o < FF_MAXO; ++o) {
+      gy[o] = 0.f;
+      if (o < O) {
+        const float yy = yo[o] + bfr[o];
+        const float dlt = yy - target[src * O + o];
+        gy[o] = gscale * dlt;
+        if (lane == o) {
+          y[row * O + o] = yy;
+          if (rec) rec[src * O + o] = yy;
+        }
+        lsum = __builtin_fmaf(dlt, dlt, lsum);
+        bsum[o] += gy[o];
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      if (!live[ps]) continue;
+      f32x4 gr = {0.f, 0.f, 0.f, 0.f}, gi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int o = 0; o < FF_MAXO; ++o)
+        if (o < O) {
+          gr += gy[o] * wre[ps][o];
+          gi += gy[o] * wim[ps][o];
+          are[ps][o] += gy[o] * zr[ps];
+          aim[ps][o] += gy[o] * zi[ps];
+        }
+      f32x4 glr, gli;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a_, b_;
+        gabor_bwd(gr[j], gi[j], lr[ps][j], li[ps][j], zr[ps][j], zi[ps][j], omega, m2s2, a_, b_);
+        glr[j] = a_; gli[j] = b_;
+      }
+      const size_t o_ = (size_t)row * P + col[ps];
+      *reinterpret_cast<f32x4*>(g_lin + o_) = glr;
+      *reinterpret_cast<f32x4*>(g_lin + o_ + 32) = gli;
+    }
+  }
+
+  // ---- combine the 4 waves: g_wf partials [O][P], bias partial [O], loss
+  float* swf = sm;                                   // [4][O][P]
+  float* sb = sm + 4 * O * P;                        // [4][FF_MAXO + 1]
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps)
+    if (live[ps])
+#pragma unroll
+      for (int o = 0; o < FF_MAXO; ++o)
+        if (o < O) {
+          *reinterpret_cast<f32x4*>(swf + ((size_t)wave * O + o) * P + col[ps]) = are[ps][o];
+          *reinterpret_cast<f32x4*>(swf + ((size_t)wave * O + o) * P + col[ps] + 32) = aim[ps][o];
+        }
+  // lsum is identical in every lane only per row-term count; every lane added the same terms -> use lane 0
+  if (lane == 0) {
+#pragma unroll
+    for (int o = 0; o < FF_MAXO; ++o) sb[wave * (FF_MAXO + 1) + o] = bsum[o];
+    sb[wave * (FF_MAXO + 1) + FF_MAXO] = lsum;
+  }
+  __syncthreads();
+  float* pw = part_w + (size_t)blockIdx.x * O * P;
+  for (int e = threadIdx.x; e < O * P; e += 256)
+    pw[e] = (swf[e] + swf[O * P + e]) + (swf[2 * O * P + e] + swf[3 * O * P + e]);
+  if (threadIdx.x < O)
+    part_b[(size_t)blockIdx.x * O + threadIdx.x] =
+        (sb[threadIdx.x] + sb[(FF_MAXO + 1) + threadIdx.x]) +
+        (sb[2 * (FF_MAXO + 1) + threadIdx.x] + sb[3 * (FF_MAXO + 1) + threadIdx.x]);
+  if (threadIdx.x == 0)
+    loss_partial[blockIdx.x] = (sb[FF_MAXO] + sb[(FF_MAXO + 1) + FF_MAXO]) +
+                               (sb[2 * (FF_MAXO + 1) + FF_MAXO] + sb[3 * (FF_MAXO + 1) + FF_MAXO]);
+}
+
+hipError_t launch_final_fused(hipStream_t s, const float* out, const float* lin, int64_t n, int P, int O,
+                              const float* wf, const float* bfr, const float* target, const int64_t* idx,
+                              int64_t first, float weight, float omega, float scale, float* y, float* rec,
+                              float* g_lin, float* part_w, float* part_b, float* loss_partial,
+                              float* loss_out) {
+  if (n <= 0) return hipSuccess;
+  if (O > FF_MAXO || !final_fused_supported(P)) return hipErrorInvalidValue;
+  const int nblk = final_bwd_blocks(n);
+  const float inv = (float)(1.0 / ((double)n * (double)O));
+  const size_t shm = ((size_t)4 * O * P + 4 * (FF_MAXO + 1)) * sizeof(float);
+  if (P <= 512)
+    hipLaunchKernelGGL(final_fused_kernel<1>, dim3((unsigned)nblk), dim3(256), shm, s, out, lin, (long long)n, P,
+                       O, wf, bfr, target, idx, (long long)first, weight * 2.f * inv, omega, scale, y, rec,
+                       g_lin, part_w, part_b, loss_partial);
+  else
+    hipLaunchKernelGGL(final_fused_kernel<2>, dim3((unsigned)nblk), dim3(256), shm, s, out, lin, (long long)n, P,
+                       O, wf, bfr, target, idx, (long long)first, weight * 2.f * inv, omega, scale, y, rec,
+                       g_lin, part_w, part_b, loss_partial);
+  // the loss partials are summed by the MSE final kernel (one block)
+  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, s, loss_partial, nblk, weight * inv, loss_out);
+  return hipGetLastError();
+}
+
 // pre-reduction of per-row-block partials: in[nblk][C] -> out[nchunk][C], chunk c sums blocks
 // [c*per, (c+1)*per).  Keeps the final reductions short (they were latency-bound over 1024 blocks).
 #define PRE_CHUNKS 32

@@ -179,16 +179,13 @@ class FusedTrainer:
                 _lib.check(L.wire_coords_from_index(stream, idx_ptr, first + mlo, n, self.tx.data_ptr(),
                                                     self.grid[1], self.ty.data_ptr(), self.grid[0],
                                                     tz_ptr, Tn, self.coords.data_ptr()), "coords")
-                _lib.check(L.wire_mlp_fwd(stream, d, self.packed.data_ptr(), self.coords.data_ptr(), n,
-                                          self.y.data_ptr(), self.act.data_ptr(), self.act_bytes, 1), "fwd")
-                _lib.check(L.wire_mse_grad(stream, self.y.data_ptr(), self.target.data_ptr(), idx_ptr,
-                                           first + mlo, n, self.O, n / float(B), self.gy.data_ptr(),
-                                           g.data_ptr() + 4 * self.count,
-                                           self.rec.data_ptr() if self.rec is not None else None,
-                                           self.partial.data_ptr()), "mse")
-                _lib.check(L.wire_mlp_bwd(stream, d, self.packed.data_ptr(), self.coords.data_ptr(), n,
-                                          self.gy.data_ptr(), self.act.data_ptr(), self.act_bytes,
-                                          self.scratch.data_ptr(), self.scr_bytes, self.grad_ptrs[m]), "bwd")
+                _lib.check(L.wire_train_fwd_bwd(
+                    stream, d, self.packed.data_ptr(), self.coords.data_ptr(), n, self.target.data_ptr(),
+                    idx_ptr, first + mlo, n / float(B), self.y.data_ptr(), self.gy.data_ptr(),
+                    g.data_ptr() + 4 * self.count,
+                    self.rec.data_ptr() if self.rec is not None else None, self.partial.data_ptr(),
+                    self.act.data_ptr(), self.act_bytes, self.scratch.data_ptr(), self.scr_bytes,
+                    self.grad_ptrs[m]), "train_fwd_bwd")
             self.reducers[m].launch()
         for r in self.reducers:
             r.wait()
