@@ -264,16 +264,54 @@ __global__ __launch_bounds__(256, 4) void gemm3m_nt_kernel(
       bb = ep.b0[feat];
       for (int d = 0; d < ep.D; ++d) w[d] = ep.W0[feat * ep.D + d];
     }
+    if (m_base + T3M <= M && !ep.wide && ep.D <= 3) {
+      // lean path: uniform bases + 32-bit byte offsets, loads of 8 rows in flight
+      const char* __restrict__ out_b = reinterpret_cast<const char*>(ep.i1);
+      const char* __restrict__ crd_b = reinterpret_cast<const char*>(ep.coords);
+      char* __restrict__ gu_b = reinterpret_cast<char*>(ep.o0);
+      const unsigned ld1b = (unsigned)ep.ld1 * 4u, ldub = (unsigned)ep.ldu * 4u, ldcb = (unsigned)ep.D * 4u;
+      const unsigned row0 = (unsigned)(m_w + 4 * h);
+      const float w0 = ep.omega;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m_w + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < M) {
-        float u = bb;
-        for (int d = 0; d < ep.D; ++d) u = __builtin_fmaf(ep.coords[(size_t)row * ep.D + d], w[d], u);
-        const size_t o1 = (size_t)row * ep.ld1;
-        const float pr = ep.i1[o1 + c_re], pi = ep.i1[o1 + c_im];
-        const float gu = gabor_bwd_real(acc[0][r] - acc[2][r], acc[0][r] + acc[1][r], u, pr, pi, ep.omega, m2s2);
-        ep.o0[(size_t)row * ep.ldu + feat] = valid ? gu : 0.f;
+      for (int rb0 = 0; rb0 < 16; rb0 += 8) {
+        float pr[8], pi[8], x0[8], x1[8], x2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = rb0 + j;
+          const unsigned row = row0 + (unsigned)((r & 3) + 8 * (r >> 2));
+          const unsigned off = row * ld1b + (unsigned)c_re * 4u;
+          pr[j] = *reinterpret_cast<const float*>(out_b + off);
+          pi[j] = *reinterpret_cast<const float*>(out_b + off + 128);
+          x0[j] = *reinterpret_cast<const float*>(crd_b + row * ldcb);
+          x1[j] = ep.D > 1 ? *reinterpret_cast<const float*>(crd_b + row * ldcb + 4) : 0.f;
+          x2[j] = ep.D > 2 ? *reinterpret_cast<const float*>(crd_b + row * ldcb + 8) : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = rb0 + j;
+          const unsigned row = row0 + (unsigned)((r & 3) + 8 * (r >> 2));
+          float u = __builtin_fmaf(x0[j], w[0], bb);
+          u = __builtin_fmaf(x1[j], w[1], u);
+          u = __builtin_fmaf(x2[j], w[2], u);
+          const float gr = acc[0][r] - acc[2][r], gi = acc[0][r] + acc[1][r];
+          const float c_r = __builtin_fmaf(pr[j], gr, pi[j] * gi);
+          const float c_i = __builtin_fmaf(pr[j], gi, -(pi[j] * gr));
+          const float gu = __builtin_fmaf(m2s2 * c_r, u, w0 * c_i);
+          *reinterpret_cast<float*>(gu_b + row * ldub + (unsigned)feat * 4u) = valid ? gu : 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m_w + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < M) {
+          float u = bb;
+          for (int d = 0; d < ep.D; ++d) u = __builtin_fmaf(ep.coords[(size_t)row * ep.D + d], w[d], u);
+          const size_t o1 = (size_t)row * ep.ld1;
+          const float pr = ep.i1[o1 + c_re], pi = ep.i1[o1 + c_im];
+          const float gu = gabor_bwd_real(acc[0][r] - acc[2][r], acc[0][r] + acc[1][r], u, pr, pi, ep.omega, m2s2);
+          ep.o0[(size_t)row * ep.ldu + feat] = valid ? gu : 0.f;
+        }
       }
     }
   }

@@ -408,20 +408,29 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
   float bsum[FF_MAXO] = {0.f, 0.f, 0.f, 0.f};
   float lsum = 0.f;
 
-  for (long long row = r0 + wave; row < r1; row += 4) {
-    f32x4 zr[NPASS], zi[NPASS], lr[NPASS], li[NPASS];
+  // software pipeline over this wave's rows: the loads of row r+4 are in flight while row r goes
+  // through its butterfly / gradient chain (one row alone keeps only 4 KB per wave in flight)
+  f32x4 nzr[NPASS], nzi[NPASS], nlr[NPASS], nli[NPASS];
+  auto load_row = [&](long long row) {
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-      zr[ps] = z4; zi[ps] = z4; lr[ps] = z4; li[ps] = z4;
-      if (live[ps]) {
+      nzr[ps] = z4; nzi[ps] = z4; nlr[ps] = z4; nli[ps] = z4;
+      if (live[ps] && row < r1) {
         const size_t o_ = (size_t)row * P + col[ps];
-        zr[ps] = *reinterpret_cast<const f32x4*>(out + o_);
-        zi[ps] = *reinterpret_cast<const f32x4*>(out + o_ + 32);
-        lr[ps] = *reinterpret_cast<const f32x4*>(lin + o_);
-        li[ps] = *reinterpret_cast<const f32x4*>(lin + o_ + 32);
+        nzr[ps] = *reinterpret_cast<const f32x4*>(out + o_);
+        nzi[ps] = *reinterpret_cast<const f32x4*>(out + o_ + 32);
+        nlr[ps] = *reinterpret_cast<const f32x4*>(lin + o_);
+        nli[ps] = *reinterpret_cast<const f32x4*>(lin + o_ + 32);
       }
     }
+  };
+  load_row(r0 + wave);
+  for (long long row = r0 + wave; row < r1; row += 4) {
+    f32x4 zr[NPASS], zi[NPASS], lr[NPASS], li[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) { zr[ps] = nzr[ps]; zi[ps] = nzi[ps]; lr[ps] = nlr[ps]; li[ps] = nli[ps]; }
+    load_row(row + 4);
     float yo[FF_MAXO];
 #pragma unroll
     for (int o = 0; o < FF_MAXO; ++o) {
