@@ -135,7 +135,7 @@ def main():
     dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
     backend = os.environ.get("WIRE_BENCH_BACKEND", "nccl")
-    if world > 1:
+    if world > 1 or os.environ.get("WIRE_DP_FORCE", "0") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":

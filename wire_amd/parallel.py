@@ -52,8 +52,12 @@ class FlatGradAllReducer:
                  bucket_floats: Optional[int] = None, use_side_stream: bool = True):
         self.flat = flat
         self.group = group
+        # WIRE_DP_FORCE=1 keeps the collective path live with a single rank (rehearsal of the RCCL
+        # stream plumbing on a one-GPU box)
+        import os
+        force = os.environ.get("WIRE_DP_FORCE", "0") == "1"
         self.active = dist.is_available() and dist.is_initialized() and \
-            dist.get_world_size(group) > 1
+            (dist.get_world_size(group) > 1 or force)
         n = flat.numel()
         if not bucket_floats or bucket_floats >= n:
             self.buckets: List[Tuple[int, int]] = [(0, n)]
