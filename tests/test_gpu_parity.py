@@ -405,6 +405,7 @@ def test_occupancy_style_minibatches_match_oracle():
     tr = FusedTrainer(model, (H, W, T), torch.tensor(vol), lr=0.0, coords_style="numpy", keep_rec=True)
     coords_all = wo.volume_coords(H, W, T)
     P64 = wo.cast_params(params_np(model), True)
+    P32 = wo.cast_params(params_np(model), False)
     perm = torch.randperm(npts)
     for b in range(0, npts, maxpoints):
         idx = perm[b:min(npts, b + maxpoints)]
@@ -414,13 +415,19 @@ def test_occupancy_style_minibatches_match_oracle():
         y64, cache = wo.wire_forward(P64, c, 3, 20.0, 20.0, 10.0, keep=True)
         l64, gy = wo.mse_loss_and_grad(y64, vol[idx.numpy()].astype(np.float64))
         g64 = wo.wire_backward(P64, cache, gy, 3, 20.0, 20.0, 10.0)
+        # the reference arithmetic in fp32 on the same minibatch: its own round-off is the yardstick
+        # (SURVEY section 7 "Precision": omega0 = 20, s0 = 10 amplifies fp32 round-off to ~1e-4)
+        y32, cache32 = wo.wire_forward(P32, c.astype(np.float32), 3, 20.0, 20.0, 10.0, keep=True)
+        _, gy32 = wo.mse_loss_and_grad(y32, vol[idx.numpy()])
+        g32 = wo.wire_backward(P32, cache32, gy32, 3, 20.0, 20.0, 10.0)
         assert abs(float(loss.item()) - l64) < 1e-4 * l64 + 1e-6
         flat = tr.flat_grad.cpu().numpy()
         names = [k for k in model.state_dict().keys() if "omega_0" not in k and "scale_0" not in k]
         for name, off, t in zip(names, tr.offsets, model.param_tensors()):
             g = wo.as_real_pairs(g64[name]).astype(np.float64).ravel()
             mine = flat[off:off + g.size]
-            assert np.abs(mine - g).max() <= 2e-4 * np.abs(g).max() + 1e-9, name
+            ref_err = np.abs(wo.as_real_pairs(g32[name]).astype(np.float64).ravel() - g).max() / np.abs(g).max()
+            assert np.abs(mine - g).max() <= max(2e-4, 4 * ref_err) * np.abs(g).max() + 1e-9, name
         np.testing.assert_allclose(tr.rec.cpu().numpy()[idx.numpy()], y64, atol=2e-4 * np.abs(y64).max())
     full = tr.render(tile=333).cpu().numpy()
     y_all = wo.wire_forward(P64, coords_all.astype(np.float64), 3, 20.0, 20.0, 10.0)

@@ -8,6 +8,8 @@
 //   ./build/gemm_tune [N] [P] [rounds]
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -15,6 +17,7 @@
 #define WIRE_ABLATE 1
 #include "../wire_amd/csrc/wire_gemm.hip"     // 4-multiplication kernels
 #include "../wire_amd/csrc/wire_gemm3m.hip"   // 3-multiplication kernels
+#include "../wire_amd/csrc/wire_gemmx3.hip"   // split-bf16 kernels
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -47,7 +50,50 @@ int main(int argc, char** argv) {
   const int S3 = gemm3m_tn_splits(N, Kp, Kp, 64);
   float* slab = dalloc((size_t)64 * P * P, 8, 0.f);
   float* bslab = dalloc((size_t)64 * P, 9, 0.f);
+  const int SX = gemmx3_tn_splits(N, P, P, 64);
+  float* Bx3; CK(hipMalloc(&Bx3, (size_t)gemmx3_b_image_floats(P, P) * 4));
+  CK(launch_x3_split_b(0, Bt, P, P, P, Bx3));
   CK(hipDeviceSynchronize());
+  // ---- correctness of the split-bf16 kernels against the fp32-MFMA ones (same operands)
+  {
+    const int64_t Nc = N < 8192 ? N : 8192;
+    GemmEpiParams ep; ep.o0 = o0; ep.ld0 = P; ep.ld1 = P;
+    CK(launch_gemm_nt(0, EPI_STORE, A, P, Bt, P, Nc, P, P, ep));
+    ep.o0 = o1;
+    CK(launch_gemmx3_nt(0, EPI_STORE, A, P, Bx3, Nc, P, P, ep));
+    std::vector<float> c0((size_t)Nc * P), c1((size_t)Nc * P);
+    CK(hipMemcpy(c0.data(), o0, c0.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(c1.data(), o1, c1.size() * 4, hipMemcpyDeviceToHost));
+    double mx = 0, md = 0;
+    for (size_t i = 0; i < c0.size(); ++i) { mx = fmax(mx, fabs(c0[i])); md = fmax(md, fabs((double)c0[i] - c1[i])); }
+    printf("check NT  x3 vs fp32-MFMA: max|diff| %.3e  max|C| %.3e  rel %.3e\n", md, mx, md / mx);
+    float* slab2; CK(hipMalloc(&slab2, (size_t)64 * P * P * 4));
+    float* bslab2; CK(hipMalloc(&bslab2, (size_t)64 * P * 4));
+    CK(launch_gemm_tn(0, A, P, out, P, Nc, P, P, 4, slab, bslab));
+    CK(launch_gemmx3_tn(0, A, P, out, P, Nc, P, P, 8, slab2, bslab2));
+    std::vector<float> s0((size_t)4 * P * P), s1((size_t)8 * P * P), b0(4 * P), b1(8 * P);
+    CK(hipMemcpy(s0.data(), slab, s0.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(s1.data(), slab2, s1.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(b0.data(), bslab, b0.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(b1.data(), bslab2, b1.size() * 4, hipMemcpyDeviceToHost));
+    mx = 0; md = 0;
+    for (size_t i = 0; i < (size_t)P * P; ++i) {
+      double a = 0, b = 0;
+      for (int q = 0; q < 4; ++q) a += s0[q * (size_t)P * P + i];
+      for (int q = 0; q < 8; ++q) b += s1[q * (size_t)P * P + i];
+      mx = fmax(mx, fabs(a)); md = fmax(md, fabs(a - b));
+    }
+    printf("check TN  x3 vs fp32-MFMA: max|diff| %.3e  max|C| %.3e  rel %.3e\n", md, mx, md / mx);
+    mx = 0; md = 0;
+    for (int i = 0; i < P; ++i) {
+      double a = 0, b = 0;
+      for (int q = 0; q < 4; ++q) a += b0[q * P + i];
+      for (int q = 0; q < 8; ++q) b += b1[q * P + i];
+      mx = fmax(mx, fabs(a)); md = fmax(md, fabs(a - b));
+    }
+    printf("check TN bias sums:        max|diff| %.3e  max %.3e\n", md, mx);
+    CK(hipFree(slab2)); CK(hipFree(bslab2));
+  }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const double flop = 2.0 * N * P * P;    // algorithmic: 8 flop per complex MAC
 
@@ -56,14 +102,15 @@ int main(int argc, char** argv) {
   std::vector<Var> vars = {
       {"4M nt gabor_fwd bk16", 0, EPI_GABOR_FWD, 16, 0}, {"4M nt gabor_bwd bk16", 0, EPI_GABOR_BWD, 16, 0},
       {"4M tn wgrad", 1, 0, 0, 0},
+      {"x3 nt store", 4, EPI_STORE, 0, 0},          {"x3 nt gabor_fwd", 4, EPI_GABOR_FWD, 0, 0},
+      {"x3 nt gabor_bwd", 4, EPI_GABOR_BWD, 0, 0},  {"x3 tn wgrad", 5, 0, 0, 0},
       {"3M nt store", 2, EPI_STORE, 0, 0},          {"3M nt gabor_fwd", 2, EPI_GABOR_FWD, 0, 0},
       {"3M nt gabor_bwd", 2, EPI_GABOR_BWD, 0, 0},  {"3M tn wgrad", 3, 0, 0, 0},
-      {"3M store noglobal", 2, EPI_STORE, 0, 1},    {"3M store nog+nolds", 2, EPI_STORE, 0, 3},
-      {"3M store nobarrier", 2, EPI_STORE, 0, 4},   {"3M store mfma only", 2, EPI_STORE, 0, 7},
-      {"3M fwd 3WG/CU", 2, EPI_GABOR_FWD, 0, 12 << 8}, {"3M fwd 2WG/CU", 2, EPI_GABOR_FWD, 0, 36 << 8},
-      {"3M fwd 1WG/CU", 2, EPI_GABOR_FWD, 0, 100 << 8}, {"3M mfma-only 1WG/CU", 2, EPI_STORE, 0, (100 << 8) | 7},
-      {"3M mfma-only 2WG/CU", 2, EPI_STORE, 0, (36 << 8) | 7},
-
+      {"x3 tall store", 4, EPI_STORE, 1, 0},        {"x3 tall gabor_fwd", 4, EPI_GABOR_FWD, 1, 0},
+      {"x3 tall gabor_bwd", 4, EPI_GABOR_BWD, 1, 0}, {"x3 tall mfma only", 4, EPI_STORE, 1, 7},
+      {"x3 tall noglobal", 4, EPI_STORE, 1, 1},
+      {"x3 store noglobal", 4, EPI_STORE, 0, 1},    {"x3 store nosplit/lds", 4, EPI_STORE, 0, 2},
+      {"x3 store nog+nolds", 4, EPI_STORE, 0, 3},   {"x3 store mfma only", 4, EPI_STORE, 0, 7},
   };
   std::vector<double> best(vars.size(), 1e30), sum(vars.size(), 0);
   for (int r = 0; r < rounds + 1; ++r) {
@@ -80,8 +127,13 @@ int main(int argc, char** argv) {
         CK(launch_gemm_tn(0, A, P, out, P, N, P, P, S, slab, bslab));
       } else if (V.kind == 2) {
         CK(launch_gemm3m_nt(0, V.epi, A, P, Bt, P, N, Kp, Kp, ep));
-      } else {
+      } else if (V.kind == 3) {
         CK(launch_gemm3m_tn(0, A, P, out, P, N, Kp, Kp, S3, slab, bslab));
+      } else if (V.kind == 4) {
+        gemmx3_tune_set("x3_tall", V.bk);
+        CK(launch_gemmx3_nt(0, V.epi, A, P, Bx3, N, P, P, ep));
+      } else {
+        CK(launch_gemmx3_tn(0, A, P, out, P, N, P, P, SX, slab, bslab));
       }
       CK(hipEventRecord(e1, 0));
       CK(hipEventSynchronize(e1));
@@ -89,11 +141,31 @@ int main(int argc, char** argv) {
       if (r > 0) { sum[v] += ms; if (ms < best[v]) best[v] = ms; }
     }
   }
+  // in-kernel clock of the split-bf16 NT kernel (s_memtime / s_memrealtime around the main loop, median over
+  // workgroups) in three states: whole kernel, without global loads, MFMA + LDS reads only
+  {
+    const int abl[3] = {64, 64 | 1, 64 | 7};
+    const char* nm[3] = {"x3 store (full)", "x3 store noglobal", "x3 store mfma only"};
+    const int nwg = (int)((N + 127) / 128 + 7) / 8 * 8 * (P / 128);
+    std::vector<unsigned long long> stamps((size_t)nwg * 2);
+    for (int v = 0; v < 3; ++v) {
+      GemmEpiParams ep; ep.o0 = o0; ep.ld0 = P; ep.ld1 = P; ep.i0 = lin; ep.ablate = abl[v];
+      gemmx3_tune_set("x3_tall", 0);
+      CK(hipMemset(lin, 0, (size_t)nwg * 16));
+      for (int r = 0; r < 20; ++r) CK(launch_gemmx3_nt(0, EPI_STORE, A, P, Bx3, N, P, P, ep));
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(stamps.data(), lin, stamps.size() * 8, hipMemcpyDeviceToHost));
+      std::vector<double> ghz;
+      for (int w = 0; w < nwg; ++w) if (stamps[2 * w + 1] > 0) ghz.push_back((double)stamps[2 * w] / (double)stamps[2 * w + 1] * 0.1);
+      std::sort(ghz.begin(), ghz.end());
+      if (!ghz.empty()) printf("clock %-20s median %.3f GHz  (p10 %.3f, p90 %.3f, %zu workgroups)\n", nm[v], ghz[ghz.size() / 2], ghz[ghz.size() / 10], ghz[ghz.size() * 9 / 10], ghz.size());
+    }
+  }
   printf("N=%lld P=%d  (%.1f algorithmic GFLOP per launch; fp32 MFMA peak 157.3 TF; 3M executes 0.75x)\n",
          (long long)N, P, flop / 1e9);
   for (size_t v = 0; v < vars.size(); ++v) {
     const double tf = flop / (sum[v] / rounds * 1e-3) / 1e12;
-    const double mf = (vars[v].kind >= 2 ? 0.75 : 1.0) * tf;   // 3M kinds execute 0.75x the flops
+    const double mf = ((vars[v].kind == 2 || vars[v].kind == 3) ? 0.75 : 1.0) * tf;   // 3M kinds execute 0.75x the flops
     printf("  %-22s mean %7.3f ms  min %7.3f ms  -> %6.1f alg TF (%5.1f%%)   MFMA busy %5.1f%%\n",
            vars[v].name, sum[v] / rounds, best[v], tf, 100.0 * tf / 157.3, 100.0 * mf / 157.3);
   }

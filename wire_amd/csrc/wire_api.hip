@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -95,11 +96,19 @@ extern "C" int wire_prof_read(double* ms_total, int64_t* launches, double* flops
 // ---------------------------------------------------------------------------
 // tuning knobs
 // ---------------------------------------------------------------------------
-static int g_complex_3m = 1;   // wire: 3-multiplication complex GEMMs (wire_gemm3m.hip)
+static int g_complex_3m = 1;   // wire: 3-multiplication complex GEMMs on the fp32 MFMA (wire_gemm3m.hip)
+static int env_flag(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? (atoi(v) != 0) : dflt;
+}
+// every net: split-bf16 GEMMs on the bf16 MFMA (wire_gemmx3.hip); overrides complex_3m
+static int g_split_bf16 = env_flag("WIRE_SPLIT_BF16", 0);
 extern "C" int wire_tune_set(const char* key, int value) {
   if (!key) return fail(WIRE_ERR_ARG, "null key");
   if (!strcmp(key, "complex_3m")) { g_complex_3m = value ? 1 : 0; return WIRE_OK; }
+  if (!strcmp(key, "split_bf16")) { g_split_bf16 = value ? 1 : 0; return WIRE_OK; }
   if (gemm_tune_set(key, value) == 0) return WIRE_OK;
+  if (gemmx3_tune_set(key, value) == 0) return WIRE_OK;
   return fail(WIRE_ERR_ARG, "unknown tuning key or bad value: %s=%d", key, value);
 }
 
@@ -112,10 +121,10 @@ inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 struct Plan {
   int kind, D, K, L, O, F;
   float w1, w, s;
-  bool cplx, first_gemm, m3;
+  bool cplx, first_gemm, m3, x3;
   int P, Pl, Din, Pin0, ldu, ntens, per_layer, Kp;
   // packed image offsets (floats); index l = 0..L (l = 0 only when first_gemm)
-  std::vector<int64_t> off_fwd, off_dg, off_bias;
+  std::vector<int64_t> off_fwd, off_dg, off_bias, off_fwd_x3, off_dg_x3;
   int64_t off_wf, off_bf, off_first, total_packed;
   std::vector<int64_t> tfloats;
 };
@@ -136,7 +145,8 @@ int make_plan(const wire_net_desc* d, Plan& p) {
   p.Pl = (p.kind == WIRE_KIND_WIRE2D) ? 2 * p.P : p.P;
   p.ldu = p.P / 2;
   p.Kp = p.P / 2;
-  p.m3 = (p.kind == WIRE_KIND_WIRE) && g_complex_3m;
+  p.x3 = g_split_bf16 != 0;
+  p.m3 = (p.kind == WIRE_KIND_WIRE) && g_complex_3m && !p.x3;
   p.first_gemm = p.F > 0;
   p.Din = p.first_gemm ? p.D + 2 * p.D * p.F : p.D;
   p.Pin0 = p.first_gemm ? rup(p.Din, 64) : 0;
@@ -157,12 +167,17 @@ int make_plan(const wire_net_desc* d, Plan& p) {
   // packed image
   int64_t off = 0;
   p.off_fwd.assign(p.L + 1, -1); p.off_dg.assign(p.L + 1, -1); p.off_bias.assign(p.L + 1, -1);
+  p.off_fwd_x3.assign(p.L + 1, -1); p.off_dg_x3.assign(p.L + 1, -1);
   for (int l = p.first_gemm ? 0 : 1; l <= p.L; ++l) {
     const int64_t pin = (l == 0) ? p.Pin0 : p.P;
-    const int64_t img = p.m3 ? (int64_t)p.Kp * p.P : (int64_t)p.Pl * pin;   // 3M keeps W itself (2 planes)
+    // sized for the largest user (the real-expanded fp32 image; the 3M planes need half of it) and with the
+    // split-bf16 images always reserved, so that a packed buffer stays valid when the tuning flags change
+    const int64_t img = (int64_t)p.Pl * pin;
     p.off_fwd[l] = off; off += img;
     p.off_dg[l] = off; off += img;
     p.off_bias[l] = off; off += p.Pl;
+    p.off_fwd_x3[l] = off; off += gemmx3_b_image_floats(p.Pl, (int)pin);
+    p.off_dg_x3[l] = off; off += gemmx3_b_image_floats((int)pin, p.Pl);
   }
   p.off_wf = off; off += (int64_t)p.O * p.P;
   p.off_bf = off; off += 64;
@@ -207,14 +222,26 @@ ScratchLayout scratch_layout(const Plan& p, int64_t n) {
   s.gb = off; off += n * p.Pl;
   s.gu = off; if (p.cplx) off += n * p.ldu * (p.kind == WIRE_KIND_WIRE2D ? 2 : 1);
   const int64_t pn = p.first_gemm && p.Pin0 > p.P ? p.Pin0 : p.P;
+  // slabs sized for the largest split count of the three GEMM families (flag-independent scratch size)
+  const int s_x3 = gemmx3_tn_splits(n, p.Pl, (int)pn, 64), s_4m = gemm_tn_splits(n, p.Pl, (int)pn, 64);
+  const int s_max = s_x3 > s_4m ? s_x3 : s_4m;
   if (p.m3) {
     s.S = gemm3m_tn_splits(n, p.Kp, p.Kp, 64);
-    s.slab = off; off += (int64_t)s.S * 3 * p.Kp * p.Kp;
-    s.bslab = off; off += (int64_t)s.S * 2 * p.Kp;
+    int64_t need = (int64_t)s.S * 3 * p.Kp * p.Kp, full = (int64_t)s_max * p.Pl * pn;
+    s.slab = off; off += need > full ? need : full;
+    need = (int64_t)s.S * 2 * p.Kp; full = (int64_t)s_max * p.Pl;
+    s.bslab = off; off += need > full ? need : full;
   } else {
-    s.S = gemm_tn_splits(n, p.Pl, (int)pn, 64);
-    s.slab = off; off += (int64_t)s.S * p.Pl * pn;
-    s.bslab = off; off += (int64_t)s.S * p.Pl;
+    s.S = p.x3 ? s_x3 : s_4m;
+    int64_t need3 = 0, needb3 = 0;
+    if (p.kind == WIRE_KIND_WIRE) {
+      const int s3 = gemm3m_tn_splits(n, p.Kp, p.Kp, 64);
+      need3 = (int64_t)s3 * 3 * p.Kp * p.Kp; needb3 = (int64_t)s3 * 2 * p.Kp;
+    }
+    int64_t full = (int64_t)s_max * p.Pl * pn;
+    s.slab = off; off += need3 > full ? need3 : full;
+    full = (int64_t)s_max * p.Pl;
+    s.bslab = off; off += needb3 > full ? needb3 : full;
   }
   const int nbf = final_bwd_blocks(n) + 32;            // + pre-reduction scratch
   s.fpw = off; off += (int64_t)nbf * p.O * p.P;
@@ -296,6 +323,10 @@ extern "C" int wire_pack_params(void* stream, const wire_net_desc* d, const void
     else
       HIPCHK(launch_pack_hidden(s, p.kind, W, b, V, c, p.K, kin, p.P, pin, packed + p.off_fwd[l],
                                 packed + p.off_dg[l], packed + p.off_bias[l]));
+    if (p.x3) {
+      HIPCHK(launch_x3_split_b(s, packed + p.off_fwd[l], pin, p.Pl, pin, packed + p.off_fwd_x3[l]));
+      HIPCHK(launch_x3_split_b(s, packed + p.off_dg[l], p.Pl, pin, p.Pl, packed + p.off_dg_x3[l]));
+    }
   }
   HIPCHK(launch_pack_final(s, p.kind, (const float*)params[p.ntens - 2],
                            (const float*)params[p.ntens - 1], p.K, p.P, p.O, packed + p.off_wf,
@@ -333,8 +364,12 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
     GemmEpiParams ep; ep.bias = packed + p.off_bias[0]; ep.o0 = lin_l(0); ep.o1 = out_l(0);
     ep.ld0 = p.Pl; ep.ld1 = p.P; ep.omega = p.w1; ep.scale = p.s; ep.kvalid = p.K;
     ProfScope ps(s, 0, 2.0 * n * p.Pl * p.Pin0);
-    HIPCHK(launch_gemm_nt(s, epi_fwd(p.kind), A + a.pe, p.Pin0, packed + p.off_fwd[0], p.Pin0, n,
-                          p.Pl, p.Pin0, ep));
+    if (p.x3)
+      HIPCHK(launch_gemmx3_nt(s, epi_fwd(p.kind), A + a.pe, p.Pin0, packed + p.off_fwd_x3[0], n, p.Pl,
+                              p.Pin0, ep));
+    else
+      HIPCHK(launch_gemm_nt(s, epi_fwd(p.kind), A + a.pe, p.Pin0, packed + p.off_fwd[0], p.Pin0, n,
+                            p.Pl, p.Pin0, ep));
   } else {
     const float* W0 = packed + first_native_off(p, 0);
     const float* b0 = packed + first_native_off(p, 1);
@@ -352,6 +387,9 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
     if (p.m3)
       HIPCHK(launch_gemm3m_nt(s, EPI_GABOR_FWD, out_l(l - 1), p.P, packed + p.off_fwd[l], p.P, n, p.Kp,
                               p.Kp, ep));
+    else if (p.x3)
+      HIPCHK(launch_gemmx3_nt(s, epi_fwd(p.kind), out_l(l - 1), p.P, packed + p.off_fwd_x3[l], n, p.Pl,
+                              p.P, ep));
     else
       HIPCHK(launch_gemm_nt(s, epi_fwd(p.kind), out_l(l - 1), p.P, packed + p.off_fwd[l], p.P, n,
                             p.Pl, p.P, ep));
@@ -430,10 +468,14 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
       ProfScope ps(s, 3, 0);
       HIPCHK(launch_wgrad3m_reduce(s, Sx + sc.slab, Sx + sc.bslab, S, p.K, p.K, p.Kp, p.Kp, gW, gb));
     } else {
-      const int S = gemm_tn_splits(n, p.Pl, p.P, sc.S);
+      const int S = p.x3 ? gemmx3_tn_splits(n, p.Pl, p.P, sc.S) : gemm_tn_splits(n, p.Pl, p.P, sc.S);
       { ProfScope ps(s, 2, 2.0 * n * p.Pl * p.P);
-        HIPCHK(launch_gemm_tn(s, gcur, p.Pl, out_l(l - 1), p.P, n, p.Pl, p.P, S, Sx + sc.slab,
-                              Sx + sc.bslab)); }
+        if (p.x3)
+          HIPCHK(launch_gemmx3_tn(s, gcur, p.Pl, out_l(l - 1), p.P, n, p.Pl, p.P, S, Sx + sc.slab,
+                                  Sx + sc.bslab));
+        else
+          HIPCHK(launch_gemm_tn(s, gcur, p.Pl, out_l(l - 1), p.P, n, p.Pl, p.P, S, Sx + sc.slab,
+                                Sx + sc.bslab)); }
       ProfScope ps(s, 3, 0);
       HIPCHK(launch_wgrad_reduce(s, p.kind, Sx + sc.slab, Sx + sc.bslab, S, p.K, p.K, p.Pl, p.P, gW,
                                  gb, gV, gc));
@@ -456,6 +498,8 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
     { ProfScope ps(s, 1, 2.0 * n * p.Pl * p.P);
       if (p.m3)
         HIPCHK(launch_gemm3m_nt(s, epi, gcur, p.P, packed + p.off_dg[l], p.P, n, p.Kp, p.Kp, ep));
+      else if (p.x3)
+        HIPCHK(launch_gemmx3_nt(s, epi, gcur, p.Pl, packed + p.off_dg_x3[l], n, p.P, p.Pl, ep));
       else
         HIPCHK(launch_gemm_nt(s, epi, gcur, p.Pl, packed + p.off_dg[l], p.Pl, n, p.P, p.Pl, ep)); }
     float* t = gcur; gcur = gnext; gnext = t;
@@ -481,9 +525,13 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
                             (float*)grads[1]));
   } else {
     const float* g0 = (p.L == 0) ? Sx + sc.ga : gcur;
-    const int S = gemm_tn_splits(n, p.P, p.Pin0, sc.S);
-    HIPCHK(launch_gemm_tn(s, g0, p.P, A + a.pe, p.Pin0, n, p.P, p.Pin0, S, Sx + sc.slab,
-                          Sx + sc.bslab));
+    const int S = p.x3 ? gemmx3_tn_splits(n, p.P, p.Pin0, sc.S) : gemm_tn_splits(n, p.P, p.Pin0, sc.S);
+    if (p.x3)
+      HIPCHK(launch_gemmx3_tn(s, g0, p.P, A + a.pe, p.Pin0, n, p.P, p.Pin0, S, Sx + sc.slab,
+                              Sx + sc.bslab));
+    else
+      HIPCHK(launch_gemm_tn(s, g0, p.P, A + a.pe, p.Pin0, n, p.P, p.Pin0, S, Sx + sc.slab,
+                            Sx + sc.bslab));
     HIPCHK(launch_wgrad_reduce(s, p.kind, Sx + sc.slab, Sx + sc.bslab, S, p.K, p.Din, p.P, p.Pin0,
                                (float*)grads[0], (float*)grads[1], nullptr, nullptr));
   }

@@ -63,3 +63,16 @@ int gemm3m_tune_set(const char* key, int value);
 int gemm3m_tn_splits(int64_t n, int Kp_o, int Kp_i, int max_splits);
 hipError_t launch_gemm3m_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n,
                             int Kp_o, int Kp_i, int splits, float* slab, float* bslab);
+
+// ---- split-bf16 GEMMs (wire_gemmx3.hip): fp32 operands split exactly into 3 bf16 terms, 6 partial
+// products on v_mfma_f32_32x32x16_bf16, fp32 accumulate.  Same operand / epilogue / slab conventions as
+// launch_gemm_nt / launch_gemm_tn, except that the weight image is the pre-split stage-major image that
+// launch_x3_split_b writes from the fp32 image Bt[Nc][ldb] (gemmx3_b_image_floats(Nc, Kd) floats).
+int64_t gemmx3_b_image_floats(int Nc, int Kd);
+hipError_t launch_x3_split_b(hipStream_t s, const float* Bt, int ldb, int Nc, int Kd, void* Bx3);
+hipError_t launch_gemmx3_nt(hipStream_t s, int epi, const float* A, int lda, const void* Bx3, int64_t M,
+                            int Nc, int Kd, const GemmEpiParams& ep);
+int gemmx3_tune_set(const char* key, int value);
+int gemmx3_tn_splits(int64_t n, int Pm, int Pn, int max_splits);
+hipError_t launch_gemmx3_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n,
+                            int Pm, int Pn, int splits, float* slab, float* bslab);

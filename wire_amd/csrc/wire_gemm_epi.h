@@ -1,0 +1,307 @@
+// wire_gemm_epi.h -- the fused epilogues of the NT GEMMs, shared by the fp32-MFMA kernel
+// (wire_gemm.hip) and the split-bf16 kernel (wire_gemmx3.hip): both leave the same accumulator image.
+//
+// accumulator element r of tile (i, j): row = m_w + 32 i + (r&3) + 8 (r>>2) + 4 h,
+// column = n_w + 32 j + (lane & 31)   (C/D map of v_mfma_f32_32x32x2_f32 and v_mfma_f32_32x32x16_bf16).
+#pragma once
+#include "wire_dev.h"
+#include "wire_gemm.h"
+
+// LEAN selects, for the Gabor epilogues of full tiles, the forms of wire_gemm3m.hip: hardware transcendentals
+// (gabor_fwd_lean), uniform base pointers with one 32-bit byte offset per accumulator row (the launcher sets
+// ep.wide when that could overflow or the leading dimensions differ), loads of 8 rows kept in flight.
+template <int EPI, int MT, int WN, bool LEAN = false>
+WIRE_DEVINL void gemm_epilogue(f32x16 (&acc)[MT][WN], const GemmEpiParams& ep, const int M, const int m_w,
+                               const int n_w, const int l31, const int h) {
+  if constexpr (LEAN && (EPI == EPI_GABOR_FWD || EPI == EPI_GABOR_BWD)) {
+    if (m_w + MT * 32 <= M && !ep.wide) {
+      const unsigned ldb4 = (unsigned)ep.ld0 * 4u;
+      bool done = true;
+      if constexpr (EPI == EPI_GABOR_FWD) {
+        // every feature of the wave's column blocks must be a real one (pad features are written as 0 below)
+        done = ((n_w >> 1) + (WN / 2) * 32) <= ep.kvalid;
+        if (done) {
+          char* __restrict__ lin_b = reinterpret_cast<char*>(ep.o0);
+          char* __restrict__ out_b = reinterpret_cast<char*>(ep.o1);
+          const float w0 = ep.omega, w0l2e = ep.omega * 1.44269502f;
+          const float ns2l2e = -(ep.scale * ep.scale) * 1.44269502f;
+#pragma unroll
+          for (int jp = 0; jp < WN; jp += 2) {
+            const int c_re = n_w + 32 * jp + l31;
+            const float b_re = ep.bias[c_re], b_im = ep.bias[c_re + 32];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+              const unsigned off0 = (unsigned)(m_w + 32 * i + 4 * h) * ldb4 + (unsigned)c_re * 4u;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const unsigned off = off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * ldb4;
+                const float u = acc[i][jp][r] + b_re, v = acc[i][jp + 1][r] + b_im;
+                float o_re, o_im;
+                gabor_fwd_lean(u, v, w0, w0l2e, ns2l2e, o_re, o_im);
+                if (lin_b) {
+                  *reinterpret_cast<float*>(lin_b + off) = u;
+                  *reinterpret_cast<float*>(lin_b + off + 128) = v;
+                }
+                *reinterpret_cast<float*>(out_b + off) = o_re;
+                *reinterpret_cast<float*>(out_b + off + 128) = o_im;
+              }
+            }
+          }
+        }
+      } else {
+        const char* __restrict__ lin_b = reinterpret_cast<const char*>(ep.i0);
+        const char* __restrict__ out_b = reinterpret_cast<const char*>(ep.i1);
+        char* __restrict__ gl_b = reinterpret_cast<char*>(ep.o0);
+        const float m2s2 = -2.f * ep.scale * ep.scale, w0 = ep.omega;
+#pragma unroll
+        for (int jp = 0; jp < WN; jp += 2) {
+          const int c_re = n_w + 32 * jp + l31;
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const unsigned off0 = (unsigned)(m_w + 32 * i + 4 * h) * ldb4 + (unsigned)c_re * 4u;
+#pragma unroll
+            for (int rb0 = 0; rb0 < 16; rb0 += 8) {
+              float lu[8], lv[8], pr[8], pi[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const int r = rb0 + j;
+                const unsigned off = off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * ldb4;
+                lu[j] = *reinterpret_cast<const float*>(lin_b + off);
+                lv[j] = *reinterpret_cast<const float*>(lin_b + off + 128);
+                pr[j] = *reinterpret_cast<const float*>(out_b + off);
+                pi[j] = *reinterpret_cast<const float*>(out_b + off + 128);
+              }
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const int r = rb0 + j;
+                const unsigned off = off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * ldb4;
+                const float gr = acc[i][jp][r], gi = acc[i][jp + 1][r];
+                const float c_r = __builtin_fmaf(pr[j], gr, pi[j] * gi);
+                const float c_i = __builtin_fmaf(pr[j], gi, -(pi[j] * gr));
+                const float t = m2s2 * c_r;
+                *reinterpret_cast<float*>(gl_b + off) = __builtin_fmaf(t, lu[j], w0 * c_i);
+                *reinterpret_cast<float*>(gl_b + off + 128) = __builtin_fmaf(t, lv[j], -(w0 * c_r));
+              }
+            }
+          }
+        }
+      }
+      if (done) return;
+    }
+  }
+  if constexpr (EPI == EPI_STORE) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int col = n_w + 32 * j + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m_w + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < M) ep.o0[(size_t)row * ep.ld0 + col] = acc[i][j][r];
+        }
+      }
+  } else if constexpr (EPI == EPI_GABOR_FWD) {
+    // tile pair (j, j+1) = (re, im) of 32 complex features
+#pragma unroll
+    for (int jp = 0; jp < WN; jp += 2) {
+      const int c_re = n_w + 32 * jp + l31;
+      const int c_im = c_re + 32;
+      const int feat = ((c_re >> 6) << 5) + l31;
+      const float b_re = ep.bias[c_re];
+      const float b_im = ep.bias[c_im];
+      const bool valid = feat < ep.kvalid;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m_w + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float u = acc[i][jp][r] + b_re;
+          const float v = acc[i][jp + 1][r] + b_im;
+          float o_re, o_im;
+          gabor_fwd(u, v, ep.omega, ep.scale, o_re, o_im);
+          if (!valid) { o_re = 0.f; o_im = 0.f; }
+          if (row < M) {
+            if (ep.o0) {
+              ep.o0[(size_t)row * ep.ld0 + c_re] = u;
+              ep.o0[(size_t)row * ep.ld0 + c_im] = v;
+            }
+            ep.o1[(size_t)row * ep.ld1 + c_re] = o_re;
+            ep.o1[(size_t)row * ep.ld1 + c_im] = o_im;
+          }
+        }
+    }
+  } else if constexpr (EPI == EPI_GABOR_BWD) {
+    const float m2s2 = -2.f * ep.scale * ep.scale;
+#pragma unroll
+    for (int jp = 0; jp < WN; jp += 2) {
+      const int c_re = n_w + 32 * jp + l31;
+      const int c_im = c_re + 32;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m_w + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < M) {
+            const size_t o0 = (size_t)row * ep.ld0;
+            const size_t o1 = (size_t)row * ep.ld1;
+            const float u = ep.i0[o0 + c_re], v = ep.i0[o0 + c_im];
+            const float pr = ep.i1[o1 + c_re], pi = ep.i1[o1 + c_im];
+            float gl_re, gl_im;
+            gabor_bwd(acc[i][jp][r], acc[i][jp + 1][r], u, v, pr, pi, ep.omega, m2s2, gl_re, gl_im);
+            ep.o0[o0 + c_re] = gl_re;
+            ep.o0[o0 + c_im] = gl_im;
+          }
+        }
+    }
+  } else if constexpr (EPI == EPI_GABOR_BWD_FIRST) {
+    const float m2s2 = -2.f * ep.scale * ep.scale;
+#pragma unroll
+    for (int jp = 0; jp < WN; jp += 2) {
+      const int c_re = n_w + 32 * jp + l31;
+      const int c_im = c_re + 32;
+      const int feat = ((c_re >> 6) << 5) + l31;
+      const bool valid = feat < ep.kvalid;
+      float w[4] = {0.f, 0.f, 0.f, 0.f};
+      float bb = 0.f;
+      if (valid) {
+        bb = ep.b0[feat];
+        for (int d = 0; d < ep.D; ++d) w[d] = ep.W0[feat * ep.D + d];
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m_w + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < M) {
+            float u = bb;
+            for (int d = 0; d < ep.D; ++d) u = __builtin_fmaf(ep.coords[(size_t)row * ep.D + d], w[d], u);
+            const size_t o1 = (size_t)row * ep.ld1;
+            const float pr = ep.i1[o1 + c_re], pi = ep.i1[o1 + c_im];
+            float gu = gabor_bwd_real(acc[i][jp][r], acc[i][jp + 1][r], u, pr, pi, ep.omega, m2s2);
+            ep.o0[(size_t)row * ep.ldu + feat] = valid ? gu : 0.f;
+          }
+        }
+    }
+  } else if constexpr (EPI == EPI_SIREN_FWD || EPI == EPI_GAUSS_FWD || EPI == EPI_RELU_FWD) {
+    constexpr int ACT = EPI - EPI_SIREN_FWD;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = n_w + 32 * j + l31;
+      const float bb = ep.bias[col];
+      const bool valid = col < ep.kvalid;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m_w + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float lin = acc[i][j][r] + bb;
+          float o = real_act_fwd<ACT>(lin, ep.omega, ep.scale);
+          if (!valid) o = 0.f;
+          if (row < M) {
+            if (ep.o0) ep.o0[(size_t)row * ep.ld0 + col] = lin;
+            ep.o1[(size_t)row * ep.ld1 + col] = o;
+          }
+        }
+    }
+  } else if constexpr (EPI == EPI_SIREN_BWD || EPI == EPI_GAUSS_BWD || EPI == EPI_RELU_BWD) {
+    constexpr int ACT = EPI - EPI_SIREN_BWD;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = n_w + 32 * j + l31;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m_w + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < M) {
+            const float lin = ep.i0[(size_t)row * ep.ld0 + col];
+            const float out = ep.i1[(size_t)row * ep.ld1 + col];
+            ep.o0[(size_t)row * ep.ld0 + col] =
+                real_act_bwd<ACT>(acc[i][j][r], lin, out, ep.omega, ep.scale);
+          }
+        }
+    }
+  } else if constexpr (EPI == EPI_GABOR2D_FWD) {
+    // wave tile = 32 rows x 128 columns = (lin_re | lin_im | sy_re | sy_im) of 32 features
+    static_assert(EPI != EPI_GABOR2D_FWD || WN == 4, "2-D Gabor needs a 128-column wave tile");
+    const int c0 = n_w + l31;                 // GEMM column of lin_re
+    const int grp = n_w >> 7;                 // feature group
+    const int feat = (grp << 5) + l31;
+    const int oc_re = (grp << 6) + l31;       // column in the P-wide output row
+    const float b_u = ep.bias[c0], b_v = ep.bias[c0 + 32], b_p = ep.bias[c0 + 64], b_q = ep.bias[c0 + 96];
+    const bool valid = feat < ep.kvalid;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m_w + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float u = acc[i][0][r] + b_u, v = acc[i][1][r] + b_v;
+        const float p = acc[i][2][r] + b_p, q = acc[i][3][r] + b_q;
+        float o_re, o_im;
+        gabor2d_fwd(u, v, p, q, ep.omega, ep.scale, o_re, o_im);
+        if (!valid) { o_re = 0.f; o_im = 0.f; }
+        if (row < M) {
+          if (ep.o0) {
+            float* L = ep.o0 + (size_t)row * ep.ld0 + c0;
+            L[0] = u; L[32] = v; L[64] = p; L[96] = q;
+          }
+          ep.o1[(size_t)row * ep.ld1 + oc_re] = o_re;
+          ep.o1[(size_t)row * ep.ld1 + oc_re + 32] = o_im;
+        }
+      }
+  } else if constexpr (EPI == EPI_GABOR2D_BWD || EPI == EPI_GABOR2D_BWD_FIRST) {
+    // C = g_out (re|im pairs, P-wide); writes g_(lin|sy) into the 2P-wide row
+    const float s2 = ep.scale * ep.scale;
+    const float m2s2 = -2.f * s2;
+#pragma unroll
+    for (int jp = 0; jp < WN; jp += 2) {
+      const int c_re = n_w + 32 * jp + l31;
+      const int grp = c_re >> 6;
+      const int feat = (grp << 5) + l31;
+      const int lc = (grp << 7) + l31;        // lin_re column in the 2P row
+      float w[4] = {0.f, 0.f, 0.f, 0.f}, wv[4] = {0.f, 0.f, 0.f, 0.f};
+      float bb = 0.f, bv = 0.f;
+      const bool valid = feat < ep.kvalid;
+      if (EPI == EPI_GABOR2D_BWD_FIRST && valid) {
+        bb = ep.b0[feat]; bv = ep.b0b[feat];
+        for (int d = 0; d < ep.D; ++d) { w[d] = ep.W0[feat * ep.D + d]; wv[d] = ep.W0b[feat * ep.D + d]; }
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m_w + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < M) {
+            const size_t o1 = (size_t)row * ep.ld1;
+            const float pr = ep.i1[o1 + c_re], pi = ep.i1[o1 + c_re + 32];
+            const float gr = acc[i][jp][r], gi = acc[i][jp + 1][r];
+            const float c_r = __builtin_fmaf(pr, gr, pi * gi);
+            const float c_i = __builtin_fmaf(pr, gi, -(pi * gr));
+            const float t = m2s2 * c_r;
+            if (EPI == EPI_GABOR2D_BWD) {
+              const float* L = ep.i0 + (size_t)row * ep.ld0 + lc;
+              const float u = L[0], v = L[32], p = L[64], q = L[96];
+              float* Gp = ep.o0 + (size_t)row * ep.ld0 + lc;
+              // g_lin = -2 s^2 P lin - j w0 c ; g_sy = -2 s^2 P sy
+              Gp[0] = __builtin_fmaf(t, u, ep.omega * c_i);
+              Gp[32] = __builtin_fmaf(t, v, -(ep.omega * c_r));
+              Gp[64] = t * p;
+              Gp[96] = t * q;
+            } else {
+              float u = bb, p = bv;
+              for (int d = 0; d < ep.D; ++d) {
+                const float x = ep.coords[(size_t)row * ep.D + d];
+                u = __builtin_fmaf(x, w[d], u);
+                p = __builtin_fmaf(x, wv[d], p);
+              }
+              // real first layer: g_u = -2 s^2 u P + w0 Im c ; g_p = -2 s^2 p P
+              float* Gp = ep.o0 + (size_t)row * (2 * ep.ldu);
+              Gp[feat] = valid ? __builtin_fmaf(t, u, ep.omega * c_i) : 0.f;
+              Gp[ep.ldu + feat] = valid ? t * p : 0.f;
+            }
+          }
+        }
+    }
+  }
+}

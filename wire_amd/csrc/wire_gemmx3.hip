@@ -1,0 +1,518 @@
+// wire_gemmx3.hip -- the GEMMs of the WIRE hot path on the bf16 matrix cores at fp32 accuracy.
+//
+// Every fp32 operand x is split exactly into three bf16 terms, x = h + m + l (round-to-nearest at each
+// level; 3 x 8 significand bits cover the 24 of fp32), and a product is accumulated from the six partial
+// products whose weight is >= 2^-16 of the leading one:
+//     a b ~= a_h b_l + a_l b_h + a_m b_m + a_h b_m + a_m b_h + a_h b_h          (dropped: <= 2^-26 |a b|)
+// Each partial product of two bf16 numbers is exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in
+// fp32, so the result carries fewer roundings than the k-ordered fmaf chain of v_mfma_f32_32x32x2_f32:
+// measured against fp64 (tools/bf16x3_numerics.hip, K = 512): rms error 0.8x, max 0.76x of the fp32 MFMA.
+// Cost: 6 bf16 MFMAs at 16x the fp32-MFMA rate = 2.67x the throughput, and -- unlike the fp32 MFMA, which
+// shares the SIMD's vector ALU (tools/mfma_valu_probe.hip) -- the bf16 matrix pipe runs beside the VALU, so
+// the splitting and the fused activation epilogues overlap with it.
+//
+// Memory formats do not change: activations stay fp32 blocked-planar rows in HBM (wire_dev.h); they are
+// split by the loader on their way into LDS (11 VALU ops per 2 elements, once per workgroup).  Weights are
+// split once per optimizer step into a stage-major bf16 image (x3_split_b_kernel).
+//
+//  gemmx3_nt_kernel : C[M][Nc] = A[M][Kd] * Bt[Nc][Kd]^T + fused epilogue (wire_gemm_epi.h), forward and
+//      data gradient.  128 x 128 tile, 4 waves of 64 x 64 (or 32 x 128), stages of 16 reduction indices,
+//      double-buffered LDS of 24 KB per stage (3 planes x (A 128 x 32 B + B 128 x 32 B)) -> 3 workgroups/CU.
+//      Operand fragments are 16-byte rows of one plane: ds_read_b128, conflict-free through an XOR of the
+//      16-byte half with bit 3 of the row.
+//  gemmx3_tn_kernel : slab[s] = G[rows_s]^T * Z[rows_s] (weight gradient; reduction over samples).  The MFMA
+//      wants 8 consecutive samples per lane while rows are feature-contiguous: the loader stores row-major
+//      bf16 planes and the fragments are read with the gfx950 transposing LDS read ds_read_b64_tr_b16.
+//
+// Replaces the ATen complex addmm / mm of modules/wire.py:89 and of its autograd backward (and the real
+// addmm of modules/siren.py:49, gauss.py:28, relu.py:29, wire2d.py:57-58).
+#include <cstdlib>
+#include <cstring>
+
+#include "wire_dev.h"
+#include "wire_gemm.h"
+#include "wire_gemm_epi.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+#define X3_BN 128
+#define X3_BK 16
+#ifndef X3_PF
+#define X3_PF 2                      // stages of global prefetch ahead of the MFMAs (1 or 2)
+#endif
+#define X3_PLANE 4096                 // bytes of one operand plane of a stage: 128 rows x 16 bf16
+
+// ---- exact three-way split of two floats into packed bf16 pairs (low half = first element)
+WIRE_DEVINL unsigned cvt_pk_bf16(float a, float b) {
+  const bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+struct Split2 { unsigned h, m, l; };
+WIRE_DEVINL Split2 split2(float x0, float x1) {
+  Split2 s;
+  s.h = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(s.h << 16), r1 = x1 - __uint_as_float(s.h & 0xffff0000u);
+  s.m = cvt_pk_bf16(r0, r1);
+  const float q0 = r0 - __uint_as_float(s.m << 16), q1 = r1 - __uint_as_float(s.m & 0xffff0000u);
+  // q has at most 8 significant bits left: the truncating pack is exact
+  s.l = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+  return s;
+}
+
+// byte offset of (row, 16-byte half) inside a 128-row x 32-byte operand plane
+WIRE_DEVINL int x3_off(int row, int half) { return row * 32 + ((half ^ ((row >> 3) & 1)) << 4); }
+
+#define X3_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+// ---------------------------------------------------------------------------
+// weights: fp32 image Bt[Nc][ldb] -> stage-major split image
+//   Bx3[col tile ct][stage kt][plane p][col c (128)][16 k]   (bf16)
+// so that the 4 KB of one (tile, stage, plane) are contiguous: thread t of the GEMM loads bytes [16 t, 16 t + 16).
+// ---------------------------------------------------------------------------
+__global__ void x3_split_b_kernel(const float* __restrict__ Bt, int ldb, int Nc, int Kd, int nk,
+                                  unsigned short* __restrict__ Bx3) {
+  const int k2 = (blockIdx.x * blockDim.x + threadIdx.x) * 2;   // pair of reduction indices
+  const int j = blockIdx.y;                                     // column, < tiles_n * 128
+  if (k2 >= Kd) return;
+  float x0 = 0.f, x1 = 0.f;
+  if (j < Nc) { x0 = Bt[(size_t)j * ldb + k2]; x1 = Bt[(size_t)j * ldb + k2 + 1]; }
+  const Split2 sp = split2(x0, x1);
+  const unsigned H = sp.h, Mi = sp.m, L = sp.l;
+  const int ct = j >> 7, c = j & 127, kt = k2 >> 4, kk = k2 & 15;
+  const size_t base = ((size_t)(ct * nk + kt) * 3 * 128 + c) * 16 + kk;
+  *reinterpret_cast<unsigned*>(Bx3 + base) = H;
+  *reinterpret_cast<unsigned*>(Bx3 + base + 128 * 16) = Mi;
+  *reinterpret_cast<unsigned*>(Bx3 + base + 2 * 128 * 16) = L;
+}
+
+int64_t gemmx3_b_image_floats(int Nc, int Kd) {
+  const int64_t tiles_n = (Nc + X3_BN - 1) / X3_BN;
+  return tiles_n * 128 * (int64_t)Kd * 3 / 2;     // 3 bf16 planes = 1.5 floats per element
+}
+
+hipError_t launch_x3_split_b(hipStream_t s, const float* Bt, int ldb, int Nc, int Kd, void* Bx3) {
+  if ((Kd & 15) || (ldb & 1)) return hipErrorInvalidValue;
+  const int tiles_n = (Nc + X3_BN - 1) / X3_BN;
+  dim3 grid((unsigned)((Kd / 2 + 127) / 128), (unsigned)(tiles_n * 128));
+  hipLaunchKernelGGL(x3_split_b_kernel, grid, dim3(128), 0, s, Bt, ldb, Nc, Kd, Kd / X3_BK,
+                     (unsigned short*)Bx3);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// NT GEMM
+// ---------------------------------------------------------------------------
+template <int EPI, int MT, int WN>
+__global__ __launch_bounds__(256, (MT * WN > 4 ? 2 : 3)) void gemmx3_nt_kernel(
+    const float* __restrict__ A, int lda, const unsigned short* __restrict__ Bx3, int M, int Nc, int Kd,
+    int tiles_m, int tiles_n, GemmEpiParams ep) {
+  constexpr int WAVES_N = X3_BN / (WN * 32);
+  constexpr int TBM = (4 / WAVES_N) * MT * 32;     // tile rows: 128 (MT = 2 or 1 x 4) or 256 (MT = 4)
+  constexpr int APLANE = TBM * 32;                 // bytes of one A plane of a stage
+  constexpr int STAGE = 3 * APLANE + 3 * X3_PLANE;
+  constexpr int NPA = TBM / 128;                   // loader passes over the A rows
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so the column tiles of
+  // one row tile run back-to-back on one L2.
+  const int b = blockIdx.x;
+  const int xcd = b & 7, idx = b >> 3;
+  const int ct = idx % tiles_n;
+  const int rt = (idx / tiles_n) * 8 + xcd;
+  if (rt >= tiles_m) return;
+  const int m_base = rt * TBM, n_base = ct * X3_BN;
+
+  // loader: thread -> (row t >> 1 (+128 per pass), half t & 1): 8 floats of A, one 16-byte piece of each B plane
+  const int lrow = tid >> 1, lhalf = tid & 1;
+  const float* a_src[NPA];
+#pragma unroll
+  for (int p = 0; p < NPA; ++p) {
+    int ra = m_base + lrow + 128 * p;
+    ra = ra < M ? ra : M - 1;
+    a_src[p] = A + (size_t)ra * lda + lhalf * 8;
+  }
+  const int nk = Kd / X3_BK;
+  const unsigned short* b_src = Bx3 + (size_t)ct * nk * (3 * 128 * 16) + tid * 8;
+  const int st_off = x3_off(lrow, lhalf);
+
+  f32x16 acc[MT][WN];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const bool wave_live = (n_base + wave_n * (WN * 32)) < Nc;
+
+  // global -> register staging, PF stages ahead of the MFMAs (register sets alternate)
+  constexpr int PF = X3_PF;
+  struct Staged { f32x4 a0[NPA], a1[NPA]; u32x4 b[3]; };
+  Staged st[PF];
+  auto gload = [&](Staged& R, int kt) {
+#pragma unroll
+    for (int p = 0; p < NPA; ++p) {
+      R.a0[p] = *reinterpret_cast<const f32x4*>(a_src[p] + kt * X3_BK);
+      R.a1[p] = *reinterpret_cast<const f32x4*>(a_src[p] + kt * X3_BK + 4);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      R.b[p] = *reinterpret_cast<const u32x4*>(b_src + (size_t)kt * (3 * 128 * 16) + p * (128 * 16));
+  };
+  auto lstore = [&](const Staged& R, int buf) {
+    unsigned char* S = smem + buf * STAGE;
+#pragma unroll
+    for (int p = 0; p < NPA; ++p) {
+      const Split2 s0 = split2(R.a0[p][0], R.a0[p][1]), s1 = split2(R.a0[p][2], R.a0[p][3]);
+      const Split2 s2 = split2(R.a1[p][0], R.a1[p][1]), s3 = split2(R.a1[p][2], R.a1[p][3]);
+      unsigned char* d = S + st_off + p * 4096;      // 128 rows on: x3_off keeps its XOR (row bit 3)
+      *reinterpret_cast<u32x4*>(d) = u32x4{s0.h, s1.h, s2.h, s3.h};
+      *reinterpret_cast<u32x4*>(d + APLANE) = u32x4{s0.m, s1.m, s2.m, s3.m};
+      *reinterpret_cast<u32x4*>(d + 2 * APLANE) = u32x4{s0.l, s1.l, s2.l, s3.l};
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(S + 3 * APLANE + p * X3_PLANE + st_off) = R.b[p];
+  };
+#ifdef WIRE_ABLATE
+  // diagnostic build only (tools/gemm_tune): stamp the shader clock and the 100 MHz reference around the main loop
+  unsigned long long t0c = 0, t0r = 0;
+  if (ep.ablate & 64) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
+#endif
+  gload(st[0], 0);
+  lstore(st[0], 0);
+  if (PF == 2) gload(st[PF - 1], 1);               // nk is even (Kd % 32 == 0)
+  __syncthreads();
+
+  int a_rd[MT], b_rd[WN];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) a_rd[i] = x3_off(wave_m * (MT * 32) + i * 32 + l31, h);
+#pragma unroll
+  for (int j = 0; j < WN; ++j) b_rd[j] = 3 * APLANE + x3_off(wave_n * (WN * 32) + j * 32 + l31, h);
+
+  // one stage: (optionally) start the global loads of stage kt + PF, MFMAs of stage kt from LDS buffer kt & 1,
+  // (optionally) split + store stage kt + 1 into the other buffer.  Branch-free inside: the main loop always
+  // loads and stores, the tail never loads (clean s_waitcnt vmcnt(N) placement: the loads of the NEXT-next
+  // stage stay in flight across the barrier).  Waves of a ragged last column tile compute on zero padding.
+  auto stage = [&](const int kt, const int u, const bool do_load, const bool do_store) {
+    const int buf = kt & 1;
+    // the set that held stage kt was stored to LDS one iteration ago: it receives stage kt + PF
+#ifdef WIRE_ABLATE
+    if (do_load && !(ep.ablate & 1)) gload(st[u], kt + PF);
+#else
+    if (do_load) gload(st[u], kt + PF);
+#endif
+    __builtin_amdgcn_sched_barrier(0);     // all loads of the stage are issued before its MFMAs
+    {
+      const unsigned char* S = smem + buf * STAGE;
+      bf16x8 af[MT][3], bf[WN][3];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(S + p * APLANE + a_rd[i]);
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(S + p * X3_PLANE + b_rd[j]);
+      // small terms first: h*l, l*h, m*m, h*m, m*h, h*h
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          X3_MFMA(af[i][0], bf[j][2], acc[i][j]);
+          X3_MFMA(af[i][2], bf[j][0], acc[i][j]);
+          X3_MFMA(af[i][1], bf[j][1], acc[i][j]);
+          X3_MFMA(af[i][0], bf[j][1], acc[i][j]);
+          X3_MFMA(af[i][1], bf[j][0], acc[i][j]);
+          X3_MFMA(af[i][0], bf[j][0], acc[i][j]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);     // ... and nothing of the split is hoisted above them
+#ifdef WIRE_ABLATE
+    if (do_store && !(ep.ablate & 2)) lstore(st[(u + 1) % PF], buf ^ 1);
+    if (!(ep.ablate & 4))
+#else
+    if (do_store) lstore(st[(u + 1) % PF], buf ^ 1);
+#endif
+    __syncthreads();
+  };
+  int kt0 = 0;
+  for (; kt0 + PF < nk; kt0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) stage(kt0 + u, u, true, true);
+  }
+#pragma unroll
+  for (int u = 0; u < PF; ++u) stage(kt0 + u, u, false, u + 1 < PF);
+#ifdef WIRE_ABLATE
+  if ((ep.ablate & 64) && tid == 0) {
+    unsigned long long* st_out = reinterpret_cast<unsigned long long*>(const_cast<float*>(ep.i0)) + (size_t)blockIdx.x * 2;
+    st_out[0] = __builtin_amdgcn_s_memtime() - t0c;
+    st_out[1] = __builtin_amdgcn_s_memrealtime() - t0r;
+  }
+#endif
+  if (!wave_live) return;
+  gemm_epilogue<EPI, MT, WN, true>(acc, ep, M, m_base + wave_m * (MT * 32), n_base + wave_n * (WN * 32), l31, h);
+}
+
+template <int EPI, int MT, int WN>
+static hipError_t launchx3_nt_t(hipStream_t s, const float* A, int lda, const void* Bx3, int64_t M, int Nc,
+                                int Kd, const GemmEpiParams& ep) {
+  constexpr int TBM = (4 / (X3_BN / (WN * 32))) * MT * 32;
+  const int tiles_m = (int)((M + TBM - 1) / TBM);
+  const int tiles_n = (Nc + X3_BN - 1) / X3_BN;
+  const int tiles_m_pad = (tiles_m + 7) & ~7;
+  hipLaunchKernelGGL((gemmx3_nt_kernel<EPI, MT, WN>), dim3((unsigned)(tiles_m_pad * tiles_n)), dim3(256), 0, s,
+                     A, lda, (const unsigned short*)Bx3, (int)M, Nc, Kd, tiles_m, tiles_n, ep);
+  return hipGetLastError();
+}
+
+static int g_x3_tall = 0;   // 256-row tiles (4 x 2 MFMA tiles per wave) for the Gabor / real epilogues
+int gemmx3_tune_set(const char* key, int value) {
+  if (!strcmp(key, "x3_tall") && (value == 0 || value == 1)) { g_x3_tall = value; return 0; }
+  return -1;
+}
+
+hipError_t launch_gemmx3_nt(hipStream_t s, int epi, const float* A, int lda, const void* Bx3, int64_t M,
+                            int Nc, int Kd, const GemmEpiParams& ep_in) {
+  if (M <= 0) return hipSuccess;
+  if ((Nc & 63) || (Kd & 31) || (lda & 3) || M > 0x7fffff00LL) return hipErrorInvalidValue;
+  // the lean Gabor epilogues share one 32-bit byte offset between their buffers
+  GemmEpiParams ep = ep_in;
+  if ((epi == EPI_GABOR_FWD || epi == EPI_GABOR_BWD) && ep.ld0 != ep.ld1) ep.wide = 1;
+  if ((double)M * (double)(ep.ld1 > ep.ld0 ? ep.ld1 : ep.ld0) * 4.0 >= 4294967296.0) ep.wide = 1;
+  if (g_x3_tall && M >= 4096) {
+    switch (epi) {
+      case EPI_STORE: return launchx3_nt_t<EPI_STORE, 4, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+      case EPI_GABOR_FWD: return launchx3_nt_t<EPI_GABOR_FWD, 4, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+      case EPI_GABOR_BWD: return launchx3_nt_t<EPI_GABOR_BWD, 4, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+      default: break;
+    }
+  }
+  switch (epi) {
+    case EPI_STORE: return launchx3_nt_t<EPI_STORE, 2, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_GABOR_FWD: return launchx3_nt_t<EPI_GABOR_FWD, 2, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_GABOR_BWD: return launchx3_nt_t<EPI_GABOR_BWD, 2, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_GABOR_BWD_FIRST: return launchx3_nt_t<EPI_GABOR_BWD_FIRST, 2, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_SIREN_FWD: return launchx3_nt_t<EPI_SIREN_FWD, 2, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_GAUSS_FWD: return launchx3_nt_t<EPI_GAUSS_FWD, 2, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_RELU_FWD: return launchx3_nt_t<EPI_RELU_FWD, 2, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_SIREN_BWD: return launchx3_nt_t<EPI_SIREN_BWD, 2, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_GAUSS_BWD: return launchx3_nt_t<EPI_GAUSS_BWD, 2, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_RELU_BWD: return launchx3_nt_t<EPI_RELU_BWD, 2, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_GABOR2D_FWD:
+      if (Nc & 127) return hipErrorInvalidValue;
+      return launchx3_nt_t<EPI_GABOR2D_FWD, 1, 4>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_GABOR2D_BWD: return launchx3_nt_t<EPI_GABOR2D_BWD, 2, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_GABOR2D_BWD_FIRST: return launchx3_nt_t<EPI_GABOR2D_BWD_FIRST, 2, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// TN GEMM: slab[split][Pm][Pn] = sum over the split's rows of G[row][m] Z[row][n];
+// bslab[split][m] = sum of G[row][m] (bias gradient; plain fp32 adds in the loader).
+// LDS plane of a stage: [16 rows][128 features] bf16, 256-byte rows whose four 64-byte chunks are
+// XOR-ed with (row & 3): the 4 rows a transposed read gathers fall on different banks.
+// ---------------------------------------------------------------------------
+#define X3_TK 16
+#define X3_TPLANE 4096                // 16 rows x 256 B
+#define X3_TSTAGE (6 * X3_TPLANE)
+
+WIRE_DEVINL s16x4 lds_tr16(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (s16x4 __attribute__((address_space(3)))*)(const_cast<unsigned char*>(p)));
+}
+
+__global__ __launch_bounds__(256, 3) void gemmx3_tn_kernel(
+    const float* __restrict__ G, int ldg, const float* __restrict__ Z, int ldz, long long n, int Pm, int Pn,
+    int tiles_n, int nsplit, long long chunk, float* __restrict__ slab, float* __restrict__ bslab, int tiles) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * X3_TSTAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  // XCD-aware order: the `tiles` output tiles of one row split read the same G/Z rows -> one L2
+  const int bb = blockIdx.x;
+  const int xcd = bb & 7, idx = bb >> 3;
+  const int tile = idx % tiles;
+  const int split = (idx / tiles) * 8 + xcd;
+  if (split >= nsplit) return;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m_base = tm * 128, n_base = tn * 128;
+  const long long row0 = (long long)split * chunk;
+  long long row1 = row0 + chunk;
+  if (row1 > n) row1 = n;
+
+  // loader: 32 threads x float4 per 128-float row, 8 rows per pass, 2 passes
+  const int lrow = tid >> 5;
+  const int lc4 = (tid & 31) * 4;
+  int gcol = m_base + lc4; if (gcol > Pm - 4) gcol = Pm - 4;
+  int zcol = n_base + lc4; if (zcol > Pn - 4) zcol = Pn - 4;
+  // byte offset of (row, feature lc4) in a plane: chunk (lc4 >> 5) ^ (row & 3); lrow + 8 p keeps row & 3
+  const int st_off = lrow * 256 + ((((lc4 >> 5) ^ (lrow & 3))) << 6) + ((lc4 & 31) << 1);
+
+  const bool live_m = (m_base + wave_m * 64) < Pm;
+  const bool live_n = (n_base + wave_n * 64) < Pn;
+  const bool wave_live = live_m && live_n;
+  const bool do_bias = (bslab != nullptr) && (tn == 0);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+  const long long nrows = row1 > row0 ? row1 - row0 : 0;
+  const int nk = (int)((nrows + X3_TK - 1) / X3_TK);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  f32x4 rg[2], rz[2];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const long long row = row0 + (long long)kt * X3_TK + lrow + 8 * p;
+      if (row < row1) {
+        rg[p] = *reinterpret_cast<const f32x4*>(G + (size_t)row * ldg + gcol);
+        rz[p] = *reinterpret_cast<const f32x4*>(Z + (size_t)row * ldz + zcol);
+      } else {
+        rg[p] = zero4;
+        rz[p] = zero4;
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* S = smem + buf * X3_TSTAGE;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      u32x2 H, Mi, L;
+      Split2 s0 = split2(rg[p][0], rg[p][1]), s1 = split2(rg[p][2], rg[p][3]);
+      H = u32x2{s0.h, s1.h}; Mi = u32x2{s0.m, s1.m}; L = u32x2{s0.l, s1.l};
+      unsigned char* d = S + st_off + p * (8 * 256);
+      *reinterpret_cast<u32x2*>(d) = H;
+      *reinterpret_cast<u32x2*>(d + X3_TPLANE) = Mi;
+      *reinterpret_cast<u32x2*>(d + 2 * X3_TPLANE) = L;
+      s0 = split2(rz[p][0], rz[p][1]); s1 = split2(rz[p][2], rz[p][3]);
+      H = u32x2{s0.h, s1.h}; Mi = u32x2{s0.m, s1.m}; L = u32x2{s0.l, s1.l};
+      *reinterpret_cast<u32x2*>(d + 3 * X3_TPLANE) = H;
+      *reinterpret_cast<u32x2*>(d + 4 * X3_TPLANE) = Mi;
+      *reinterpret_cast<u32x2*>(d + 5 * X3_TPLANE) = L;
+      if (do_bias) bsum += rg[p];
+    }
+  };
+
+  if (nk > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+
+  // transposed fragment reads: lane -> group g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3:
+  // row 8 (g >> 1) + q (+4 for the second read), features 16 (g & 1) + 4 p of the wave's 32-feature block
+  const int q = (lane >> 2) & 3;
+  const int rd_lane = (8 * h + q) * 256 + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+  int g_rd[2], z_rd[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    g_rd[i] = rd_lane + ((((wave_m * 2 + i) ^ q)) << 6);
+    z_rd[i] = 3 * X3_TPLANE + rd_lane + ((((wave_n * 2 + i) ^ q)) << 6);
+  }
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const bool more = (kt + 1) < nk;
+    if (more) gload(kt + 1);
+    if (wave_live) {
+      const unsigned char* S = smem + buf * X3_TSTAGE;
+      bf16x8 gf[2][3], zf[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const s16x4 g0 = lds_tr16(S + p * X3_TPLANE + g_rd[i]);
+          const s16x4 g1 = lds_tr16(S + p * X3_TPLANE + g_rd[i] + 4 * 256);
+          const s16x4 z0 = lds_tr16(S + p * X3_TPLANE + z_rd[i]);
+          const s16x4 z1 = lds_tr16(S + p * X3_TPLANE + z_rd[i] + 4 * 256);
+          gf[i][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
+          zf[i][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(z0, z1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          X3_MFMA(gf[i][0], zf[j][2], acc[i][j]);
+          X3_MFMA(gf[i][2], zf[j][0], acc[i][j]);
+          X3_MFMA(gf[i][1], zf[j][1], acc[i][j]);
+          X3_MFMA(gf[i][0], zf[j][1], acc[i][j]);
+          X3_MFMA(gf[i][1], zf[j][0], acc[i][j]);
+          X3_MFMA(gf[i][0], zf[j][0], acc[i][j]);
+        }
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (do_bias) {
+    // 8 loader threads (tid & 31 equal) share a feature quad: sum them through LDS (all reads are done)
+    float* red = reinterpret_cast<float*>(smem);
+    *reinterpret_cast<f32x4*>(&red[lrow * 128 + lc4]) = bsum;
+    __syncthreads();
+    if (tid < 128) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v += red[r * 128 + tid];
+      const int m = m_base + tid;
+      if (m < Pm) bslab[(size_t)split * Pm + m] = v;
+    }
+  }
+  if (!wave_live) return;
+  float* out = slab + (size_t)split * Pm * Pn;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n_base + wave_n * 64 + 32 * j + l31;
+      if (col < Pn) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m_base + wave_m * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < Pm) out[(size_t)m * Pn + col] = acc[i][j][r];
+        }
+      }
+    }
+}
+
+int gemmx3_tn_splits(int64_t n, int Pm, int Pn, int max_splits) {
+  const int tiles = ((Pm + 127) / 128) * ((Pn + 127) / 128);
+  int s = (768 + tiles - 1) / tiles;          // ~3 workgroups per CU
+  int64_t by_rows = (n + 255) / 256;          // at least 256 rows per split
+  if (by_rows < 1) by_rows = 1;
+  if (s > by_rows) s = (int)by_rows;
+  if (s > max_splits) s = max_splits;
+  if (s < 1) s = 1;
+  return s;
+}
+
+hipError_t launch_gemmx3_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n,
+                            int Pm, int Pn, int splits, float* slab, float* bslab) {
+  // ragged tiles clamp their loader column to P - 4, which needs whole 128-feature tiles or P >= 128 handled
+  // by the clamp: the kernel requires Pm, Pn multiples of 64 (all padded widths are)
+  if ((Pm & 63) || (Pn & 63) || (ldg & 3) || (ldz & 3) || splits < 1) return hipErrorInvalidValue;
+  const int tiles_m = (Pm + 127) / 128, tiles_n = (Pn + 127) / 128;
+  long long chunk = (n + splits - 1) / splits;
+  chunk = (chunk + X3_TK - 1) / X3_TK * X3_TK;
+  if (chunk < X3_TK) chunk = X3_TK;
+  const int splits_pad = (splits + 7) & ~7;
+  hipLaunchKernelGGL(gemmx3_tn_kernel, dim3((unsigned)(tiles_m * tiles_n * splits_pad)), dim3(256), 0, s, G, ldg,
+                     Z, ldz, (long long)n, Pm, Pn, tiles_n, splits, chunk, slab, bslab, tiles_m * tiles_n);
+  return hipGetLastError();
+}
