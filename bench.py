@@ -15,9 +15,13 @@ on-device coordinates -> forward -> MSE -> backward -> all-reduce -> Adam.
 Synthetic data (U[0,1) target), reference init under torch.manual_seed(0).
 
 The JSON line also carries
-  roofline     : dominant kernel class (fp32-MFMA GEMMs) timed live with HIP
-                 events on the launch stream; algorithmic flops (8 flop per
-                 complex MAC) / average launch duration vs 157.3 TFLOP/s.
+  roofline     : dominant kernel class (the layer GEMMs) timed live with HIP
+                 events on the launch stream; achieved = algorithmic flops (8
+                 flop per complex MAC) / average launch duration.
+                 Default path (split-bf16, wire_gemmx3.hip): every fp32 product
+                 is 6 bf16 MFMA products, so the ceiling of the algorithm is
+                 the dense bf16 MFMA peak / 6 = 416.7 fp32-equivalent TFLOP/s;
+                 with WIRE_SPLIT_BF16=0 (fp32-MFMA kernels) it is 157.3.
   cpu_baseline : the oracle's eager-PyTorch restatement of the reference's CPU
                  path (kind "port"), timed on this host's cores on a bounded
                  sample of the same workload.
@@ -37,6 +41,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 256 flop/clk x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (16x the fp32 MFMA rate)
 HIDDEN_FEATURES = 363           # -> K = int(363/sqrt(2)) = 256 complex features
 L, D, O = 4, 2, 3
 OMEGA0, SIGMA0 = 20.0, 30.0
@@ -197,8 +202,15 @@ def main():
         n_gpu_batch = npts // world
         F = 24 * K * K * L + 4 * D * K + 12 * K * O      # SURVEY 8(d) algorithmic flop / sample
         value = npts * args.steps / dt
-        names = ["gemm3m_nt<gabor_fwd> (layer forward)", "gemm3m_nt<gabor_bwd> (data gradient)",
-                 "gemm3m_tn (weight gradient)", "other"]
+        split = lib.wire_tune_get(b"split_bf16") == 1
+        if split:
+            names = ["gemmx3_nt<gabor_fwd> (layer forward)", "gemmx3_nt<gabor_bwd> (data gradient)",
+                     "gemmx3_tn (weight gradient)", "other"]
+            peak = PEAK_BF16_MFMA_TFLOPS / 6.0          # 6 bf16 partial products per fp32 product
+        else:
+            names = ["gemm3m_nt<gabor_fwd> (layer forward)", "gemm3m_nt<gabor_bwd> (data gradient)",
+                     "gemm3m_tn (weight gradient)", "other"]
+            peak = PEAK_FP32_MFMA_TFLOPS
         alg_per_launch = 8.0 * K * K * (n_gpu_batch / max(1, args.micro_shards))   # per hidden-layer GEMM
         klass = max(range(3), key=lambda i: ms[i])
         avg_ms = ms[klass] / max(1, cnt[klass])
@@ -207,23 +219,29 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(str(klass))
+                tj = json.load(open(tpath))
+                traffic = (tj.get("split_bf16", {}) if split else tj.get("fp32_mfma", tj)).get(str(klass))
             except Exception:
                 traffic = None
         out = {
             "metric": "coord-samples/sec fwd+bwd, 4x256 complex WIRE MLP",
             "value": value, "unit": "coord-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (3xbf16 split operands, bf16 MFMA, fp32 accumulate)" if split else "f32",
+            "data": "synthetic",
             "config": {"workload": f"512x{512 * world} image fit, WIRE 4 hidden x {K} complex "
                                    f"(hidden_features={args.hidden_features}), D=2 O=3 omega0=20 sigma0=30, "
                                    f"batch=262144 coords/GPU, fwd+MSE+bwd+Adam per step",
                        "global_batch": npts, "parallelism": f"dp{world}", "micro_shards": args.micro_shards},
             "roofline": {"bound": "mfma", "kernel": names[klass], "achieved": achieved,
-                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": int(cnt[klass]),
-                         "alg_flops_per_launch": alg_per_launch},
+                         "alg_flops_per_launch": alg_per_launch,
+                         "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per fp32 product; "
+                                       "executed bf16 rate = 6 x achieved") if split else "fp32 MFMA peak",
+                         "executed_mfma_tflops": achieved * (6.0 if split else 0.75),
+                         "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS},
             "whole_step_tflops": value / world * F / 1e12,
             "whole_step_frac_of_fp32_mfma_peak": value / world * F / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             "kernel_ms_per_step": {names[i]: ms[i] / args.steps for i in range(4)},

@@ -206,12 +206,21 @@ int wire_c64_to_blocked(void* stream, const void* src, int64_t n, int K, float* 
 int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* dst);
 
 /* ---- tuning knobs ---------------------------------------------------------
- * "complex_3m" (default 1): wire layers use the 3-multiplication complex GEMMs
- *     (6 real flop per complex MAC on the matrix cores); 0 = 4-multiplication
- *     real-expanded GEMMs.  Packed images differ: re-run wire_pack_params (and
- *     re-query the size functions) after changing it.
- * "nt_bk" (16 | 32): K-slab depth of the 4-multiplication NT kernel.          */
+ * "split_bf16" (default 1; environment WIRE_SPLIT_BF16): every GEMM of every net
+ *     kind runs on the bf16 matrix cores with each fp32 operand split exactly into
+ *     three bf16 terms (6 partial products, fp32 accumulate; fp32-accurate --
+ *     wire_gemmx3.hip).  0 = the fp32-MFMA kernels below.
+ * "complex_3m" (default 1; used when split_bf16 = 0): wire layers use the
+ *     3-multiplication complex GEMMs on the fp32 MFMA (6 real flop per complex
+ *     MAC); 0 = 4-multiplication real-expanded GEMMs.
+ * "x3_tall" (default 1), "x3_tn_tall" (default 0): 256-row tiles in the split-bf16
+ *     NT / TN kernels.   "nt_bk" (16 | 32): K-slab depth of the fp32 4M NT kernel.
+ * Buffer sizes (wire_packed_floats, wire_act_bytes, wire_bwd_scratch_bytes) do not
+ * depend on the knobs; the CONTENT of a packed buffer does: re-run
+ * wire_pack_params after changing one, and do not change one between a forward
+ * and its backward.                                                            */
 int wire_tune_set(const char* key, int value);
+int wire_tune_get(const char* key);   /* "split_bf16" | "complex_3m" -> value; < 0 = error */
 
 /* ---- profiling hooks (bench.py roofline) -------------------------------
  * When enabled, every launch of the hot kernels is bracketed by hipEvents on

@@ -78,30 +78,65 @@ def test_full_configs(name):
         assert np.abs(head - rec["g64head:" + k]).max() <= (4 * ref_err + 3e-6) * scale, k
 
 
-def test_complex_3m_vs_4m_accuracy():
-    """The 3-multiplication complex GEMM (default) and the 4-multiplication one both
-    meet the parity bar, and 3M is not materially less accurate (normwise-stable;
-    its extra cancellation shows up as a small constant factor)."""
+def _set_family(L, split_bf16, complex_3m):
+    from wire_amd import _lib
+    _lib.check(L.wire_tune_set(b"split_bf16", split_bf16))
+    _lib.check(L.wire_tune_set(b"complex_3m", complex_3m))
+
+
+def test_gemm_families_accuracy():
+    """Three GEMM families serve the wire layers: split-bf16 on the bf16 MFMA (default), the
+    3-multiplication complex product on the fp32 MFMA, the 4-multiplication real-expanded fp32 MFMA.
+    Each meets the parity bar on its own, and neither the split nor the 3M form is materially less
+    accurate than the plain fp32-MFMA product (the split carries FEWER roundings: tools/bf16x3_numerics.hip)."""
     from wire_amd import _lib
     L = _lib.lib()
+    assert L.wire_tune_get(b"split_bf16") == 1 or "WIRE_SPLIT_BF16" in __import__("os").environ
     errs = {}
+    fams = {"4m": (0, 0), "3m": (0, 1), "x3": (1, 1)}
     try:
-        for mode in (0, 1):
-            _lib.check(L.wire_tune_set(b"complex_3m", mode))
+        for fam, (sb, c3) in fams.items():
+            _set_family(L, sb, c3)
             for name in ("small_wire_hi", "full_cfg2_wire_4x363_lit"):
                 rec = load_golden(name)
                 model = load_small(rec, build_model(rec)) if name.startswith("small") else build_model(rec).to(DEV)
                 y, loss, grads = hip_forward_backward(model, rec)
                 err_ref = relmax(rec["y"], rec["y64"])
                 e = relmax(y, rec["y64"])
-                assert e <= 4 * err_ref + 3e-6, (mode, name)
-                errs[(mode, name)] = (e, err_ref)
+                assert e <= 4 * err_ref + 3e-6, (fam, name)
+                errs[(fam, name)] = (e, err_ref)
     finally:
-        _lib.check(L.wire_tune_set(b"complex_3m", 1))
+        _set_family(L, 1, 1)
     for name in ("small_wire_hi", "full_cfg2_wire_4x363_lit"):
-        e4, e3 = errs[(0, name)][0], errs[(1, name)][0]
-        print(f"{name}: err 4M {e4:.3e}  3M {e3:.3e}  reference fp32 {errs[(0, name)][1]:.3e}")
+        e4, e3, ex = errs[("4m", name)][0], errs[("3m", name)][0], errs[("x3", name)][0]
+        print(f"{name}: err 4M {e4:.3e}  3M {e3:.3e}  split-bf16 {ex:.3e}  reference fp32 {errs[('4m', name)][1]:.3e}")
         assert e3 <= 3 * e4 + 1e-6
+        assert ex <= 3 * e4 + 1e-6
+
+
+@pytest.mark.parametrize("name", ["full_cfg2_wire_4x256_api", "full_cfg4_wire2d_4x256", "full_cfg5_siren_4x256",
+                                  "full_cfg5_posenc_4x256"])
+def test_fp32_mfma_family_full_configs(name):
+    """The fp32-MFMA kernels (split_bf16 = 0) stay covered: same bar as test_full_configs."""
+    from wire_amd import _lib
+    L = _lib.lib()
+    if name not in FULL:
+        pytest.skip(f"no fixture {name}")
+    try:
+        _set_family(L, 0, 1)
+        rec = load_golden(name)
+        model = build_model(rec).to(DEV)
+        P = params_np(model)
+        y, loss, grads = hip_forward_backward(model, rec)
+        err_ref = relmax(rec["y"], rec["y64"])
+        assert relmax(y, rec["y64"]) <= 4 * err_ref + 3e-6
+        _, _, g64, _ = oracle_run(rec, P, double=True)
+        _, _, g32, _ = oracle_run(rec, P, double=False)
+        for k, g in grads.items():
+            ref_err = relmax(g32[k], g64[k]) + 0.05 * err_ref
+            assert relmax(g, g64[k]) <= 4 * ref_err + 3e-6, k
+    finally:
+        _set_family(L, 1, 1)
 
 
 @pytest.mark.parametrize("name", ["small_wire_d2", "small_wire_d3", "small_wire_hi"])

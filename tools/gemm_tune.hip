@@ -69,8 +69,9 @@ int main(int argc, char** argv) {
     printf("check NT  x3 vs fp32-MFMA: max|diff| %.3e  max|C| %.3e  rel %.3e\n", md, mx, md / mx);
     float* slab2; CK(hipMalloc(&slab2, (size_t)64 * P * P * 4));
     float* bslab2; CK(hipMalloc(&bslab2, (size_t)64 * P * 4));
-    CK(launch_gemm_tn(0, A, P, out, P, Nc, P, P, 4, slab, bslab));
-    CK(launch_gemmx3_tn(0, A, P, out, P, Nc, P, P, 8, slab2, bslab2));
+    CK(launch_gemm_tn(0, A, P, out, P, Nc - 5, P, P, 4, slab, bslab));
+    gemmx3_tune_set("x3_tn_tall", argc > 4 ? atoi(argv[4]) : 0);
+    CK(launch_gemmx3_tn(0, A, P, out, P, Nc - 5, P, P, 8, slab2, bslab2));   // ragged row count
     std::vector<float> s0((size_t)4 * P * P), s1((size_t)8 * P * P), b0(4 * P), b1(8 * P);
     CK(hipMemcpy(s0.data(), slab, s0.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(s1.data(), slab2, s1.size() * 4, hipMemcpyDeviceToHost));
@@ -106,9 +107,11 @@ int main(int argc, char** argv) {
       {"x3 nt gabor_bwd", 4, EPI_GABOR_BWD, 0, 0},  {"x3 tn wgrad", 5, 0, 0, 0},
       {"3M nt store", 2, EPI_STORE, 0, 0},          {"3M nt gabor_fwd", 2, EPI_GABOR_FWD, 0, 0},
       {"3M nt gabor_bwd", 2, EPI_GABOR_BWD, 0, 0},  {"3M tn wgrad", 3, 0, 0, 0},
+      {"x3 tn tall wgrad", 5, 0, 1, 0},
       {"x3 tall store", 4, EPI_STORE, 1, 0},        {"x3 tall gabor_fwd", 4, EPI_GABOR_FWD, 1, 0},
       {"x3 tall gabor_bwd", 4, EPI_GABOR_BWD, 1, 0}, {"x3 tall mfma only", 4, EPI_STORE, 1, 7},
       {"x3 tall noglobal", 4, EPI_STORE, 1, 1},
+      {"x3 store no A loads", 4, EPI_STORE, 0, 128}, {"x3 store no B loads", 4, EPI_STORE, 0, 256},
       {"x3 store noglobal", 4, EPI_STORE, 0, 1},    {"x3 store nosplit/lds", 4, EPI_STORE, 0, 2},
       {"x3 store nog+nolds", 4, EPI_STORE, 0, 3},   {"x3 store mfma only", 4, EPI_STORE, 0, 7},
   };
@@ -133,6 +136,7 @@ int main(int argc, char** argv) {
         gemmx3_tune_set("x3_tall", V.bk);
         CK(launch_gemmx3_nt(0, V.epi, A, P, Bx3, N, P, P, ep));
       } else {
+        gemmx3_tune_set("x3_tn_tall", V.bk);
         CK(launch_gemmx3_tn(0, A, P, out, P, N, P, P, SX, slab, bslab));
       }
       CK(hipEventRecord(e1, 0));

@@ -102,7 +102,13 @@ static int env_flag(const char* name, int dflt) {
   return v ? (atoi(v) != 0) : dflt;
 }
 // every net: split-bf16 GEMMs on the bf16 MFMA (wire_gemmx3.hip); overrides complex_3m
-static int g_split_bf16 = env_flag("WIRE_SPLIT_BF16", 0);
+static int g_split_bf16 = env_flag("WIRE_SPLIT_BF16", 1);
+extern "C" int wire_tune_get(const char* key) {
+  if (!key) return fail(WIRE_ERR_ARG, "null key");
+  if (!strcmp(key, "complex_3m")) return g_complex_3m;
+  if (!strcmp(key, "split_bf16")) return g_split_bf16;
+  return fail(WIRE_ERR_ARG, "unknown tuning key: %s", key);
+}
 extern "C" int wire_tune_set(const char* key, int value) {
   if (!key) return fail(WIRE_ERR_ARG, "null key");
   if (!strcmp(key, "complex_3m")) { g_complex_3m = value ? 1 : 0; return WIRE_OK; }

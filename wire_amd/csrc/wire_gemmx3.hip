@@ -41,6 +41,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #define X3_BN 128
 #define X3_BK 16
+#ifndef X3_TN_PF
+#define X3_TN_PF 1                   // the same for the weight-gradient kernel (register budget)
+#endif
 #ifndef X3_PF
 #define X3_PF 2                      // stages of global prefetch ahead of the MFMAs (1 or 2)
 #endif
@@ -158,11 +161,17 @@ __global__ __launch_bounds__(256, (MT * WN > 4 ? 2 : 3)) void gemmx3_nt_kernel(
   struct Staged { f32x4 a0[NPA], a1[NPA]; u32x4 b[3]; };
   Staged st[PF];
   auto gload = [&](Staged& R, int kt) {
+#ifdef WIRE_ABLATE
+    if (!(ep.ablate & 128))
+#endif
 #pragma unroll
     for (int p = 0; p < NPA; ++p) {
       R.a0[p] = *reinterpret_cast<const f32x4*>(a_src[p] + kt * X3_BK);
       R.a1[p] = *reinterpret_cast<const f32x4*>(a_src[p] + kt * X3_BK + 4);
     }
+#ifdef WIRE_ABLATE
+    if (!(ep.ablate & 256))
+#endif
 #pragma unroll
     for (int p = 0; p < 3; ++p)
       R.b[p] = *reinterpret_cast<const u32x4*>(b_src + (size_t)kt * (3 * 128 * 16) + p * (128 * 16));
@@ -234,12 +243,24 @@ __global__ __launch_bounds__(256, (MT * WN > 4 ? 2 : 3)) void gemmx3_nt_kernel(
           X3_MFMA(af[i][0], bf[j][0], acc[i][j]);
         }
     }
-    __builtin_amdgcn_sched_barrier(0);     // ... and nothing of the split is hoisted above them
 #ifdef WIRE_ABLATE
     if (do_store && !(ep.ablate & 2)) lstore(st[(u + 1) % PF], buf ^ 1);
-    if (!(ep.ablate & 4))
 #else
     if (do_store) lstore(st[(u + 1) % PF], buf ^ 1);
+#endif
+    // issue order: the split of the next stage (VALU) and its LDS stores ride in the shadow of this stage's
+    // MFMAs -- 2 vector ops after every MFMA, one ds_write after every fourth (MI355X guide: <= 5 single-issue
+    // instructions hide per v_mfma_f32_32x32x16_bf16)
+    if (do_store) {
+#pragma unroll
+      for (int g = 0; g < MT * WN * 6; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, (NPA * 44 + MT * WN * 6 - 1) / (MT * WN * 6) + 1, 0);
+        if ((g & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, (NPA * 3 + 3 + 5) / 6, 0);
+      }
+    }
+#ifdef WIRE_ABLATE
+    if (!(ep.ablate & 4))
 #endif
     __syncthreads();
   };
@@ -273,9 +294,17 @@ static hipError_t launchx3_nt_t(hipStream_t s, const float* A, int lda, const vo
   return hipGetLastError();
 }
 
-static int g_x3_tall = 0;   // 256-row tiles (4 x 2 MFMA tiles per wave) for the Gabor / real epilogues
+static int x3_env(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+static int g_x3_tn_tall = x3_env("WIRE_X3_TN_TALL", 0);   // 256 x 128 tiles in the weight-gradient kernel
+// 256-row tiles (4 x 2 MFMA tiles per wave) for the Gabor epilogues of large batches: fewer weight bytes
+// per MFMA through the 64 B/clk L1 path (tools/mfma_bf16_probe.hip), 7-9 % faster at N = 262144
+static int g_x3_tall = x3_env("WIRE_X3_TALL", 1);
 int gemmx3_tune_set(const char* key, int value) {
   if (!strcmp(key, "x3_tall") && (value == 0 || value == 1)) { g_x3_tall = value; return 0; }
+  if (!strcmp(key, "x3_tn_tall") && (value == 0 || value == 1)) { g_x3_tn_tall = value; return 0; }
   return -1;
 }
 
@@ -322,18 +351,25 @@ hipError_t launch_gemmx3_nt(hipStream_t s, int epi, const float* A, int lda, con
 // XOR-ed with (row & 3): the 4 rows a transposed read gathers fall on different banks.
 // ---------------------------------------------------------------------------
 #define X3_TK 16
-#define X3_TPLANE 4096                // 16 rows x 256 B
-#define X3_TSTAGE (6 * X3_TPLANE)
 
 WIRE_DEVINL s16x4 lds_tr16(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (s16x4 __attribute__((address_space(3)))*)(const_cast<unsigned char*>(p)));
 }
 
-__global__ __launch_bounds__(256, 3) void gemmx3_tn_kernel(
+// MT = 32-feature blocks of G per wave (2 or 4): the tile is (64 MT) features of G x 128 features of Z
+template <int MT>
+__global__ __launch_bounds__(256, (MT > 2 ? 2 : 3)) void gemmx3_tn_kernel(
     const float* __restrict__ G, int ldg, const float* __restrict__ Z, int ldz, long long n, int Pm, int Pn,
     int tiles_n, int nsplit, long long chunk, float* __restrict__ slab, float* __restrict__ bslab, int tiles) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * X3_TSTAGE];
+  constexpr int TM = 64 * MT;                  // G features per tile
+  constexpr int GROW = TM * 2;                 // bytes of a G row in LDS (bf16)
+  constexpr int GPLANE = X3_TK * GROW, ZPLANE = X3_TK * 256;
+  constexpr int TSTAGE = 3 * GPLANE + 3 * ZPLANE;
+  constexpr int G_TPR = TM / 4;                // loader threads per G row
+  constexpr int G_RPP = 256 / G_TPR;           // G rows per loader pass (8 or 4)
+  constexpr int G_NP = X3_TK / G_RPP;          // passes (2 or 4)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TSTAGE];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wave_m = wave >> 1, wave_n = wave & 1;
@@ -345,108 +381,121 @@ __global__ __launch_bounds__(256, 3) void gemmx3_tn_kernel(
   const int split = (idx / tiles) * 8 + xcd;
   if (split >= nsplit) return;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
-  const int m_base = tm * 128, n_base = tn * 128;
+  const int m_base = tm * TM, n_base = tn * 128;
   const long long row0 = (long long)split * chunk;
   long long row1 = row0 + chunk;
   if (row1 > n) row1 = n;
+  if (row1 <= row0) return;                    // (cannot happen: chunk * nsplit covers n with no empty split)
 
-  // loader: 32 threads x float4 per 128-float row, 8 rows per pass, 2 passes
-  const int lrow = tid >> 5;
-  const int lc4 = (tid & 31) * 4;
-  int gcol = m_base + lc4; if (gcol > Pm - 4) gcol = Pm - 4;
-  int zcol = n_base + lc4; if (zcol > Pn - 4) zcol = Pn - 4;
-  // byte offset of (row, feature lc4) in a plane: chunk (lc4 >> 5) ^ (row & 3); lrow + 8 p keeps row & 3
-  const int st_off = lrow * 256 + ((((lc4 >> 5) ^ (lrow & 3))) << 6) + ((lc4 & 31) << 1);
+  // loaders: a float4 of one row per thread and pass; (row & 3) is the same in every pass
+  const int g_lrow = tid / G_TPR, g_lc4 = (tid % G_TPR) * 4;
+  const int z_lrow = tid >> 5, z_lc4 = (tid & 31) * 4;
+  int gcol = m_base + g_lc4; if (gcol > Pm - 4) gcol = Pm - 4;      // ragged last tile: stay in the row
+  int zcol = n_base + z_lc4; if (zcol > Pn - 4) zcol = Pn - 4;
+  const int g_st = g_lrow * GROW + ((((g_lc4 >> 5) ^ (g_lrow & 3))) << 6) + ((g_lc4 & 31) << 1);
+  const int z_st = 3 * GPLANE + z_lrow * 256 + ((((z_lc4 >> 5) ^ (z_lrow & 3))) << 6) + ((z_lc4 & 31) << 1);
 
-  const bool live_m = (m_base + wave_m * 64) < Pm;
+  const bool live_m = (m_base + wave_m * (32 * MT)) < Pm;
   const bool live_n = (n_base + wave_n * 64) < Pn;
   const bool wave_live = live_m && live_n;
   const bool do_bias = (bslab != nullptr) && (tn == 0);
 
-  f32x16 acc[2][2];
+  f32x16 acc[MT][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
-  const long long nrows = row1 > row0 ? row1 - row0 : 0;
-  const int nk = (int)((nrows + X3_TK - 1) / X3_TK);
+  const int nk = (int)((row1 - row0 + X3_TK - 1) / X3_TK);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  f32x4 rg[2], rz[2];
-  auto gload = [&](int kt) {
+  constexpr int PF = X3_TN_PF;
+  struct Staged { f32x4 g[G_NP], z[2]; };
+  Staged st[PF];
+  // rows past the split's end are read from its last row (no branch around the loads) and zeroed when the
+  // stage is split and stored -- not here, where the select would wait for the load
+  auto gload = [&](Staged& R, int kt) {
+    const long long rb = row0 + (long long)kt * X3_TK;
+#pragma unroll
+    for (int p = 0; p < G_NP; ++p) {
+      const long long row = rb + g_lrow + G_RPP * p;
+      const bool ok = row < row1;
+      R.g[p] = *reinterpret_cast<const f32x4*>(G + (size_t)(ok ? row : row1 - 1) * ldg + gcol);
+    }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const long long row = row0 + (long long)kt * X3_TK + lrow + 8 * p;
-      if (row < row1) {
-        rg[p] = *reinterpret_cast<const f32x4*>(G + (size_t)row * ldg + gcol);
-        rz[p] = *reinterpret_cast<const f32x4*>(Z + (size_t)row * ldz + zcol);
-      } else {
-        rg[p] = zero4;
-        rz[p] = zero4;
-      }
+      const long long row = rb + z_lrow + 8 * p;
+      const bool ok = row < row1;
+      R.z[p] = *reinterpret_cast<const f32x4*>(Z + (size_t)(ok ? row : row1 - 1) * ldz + zcol);
     }
   };
-  auto lstore = [&](int buf) {
-    unsigned char* S = smem + buf * X3_TSTAGE;
+  auto lstore = [&](const Staged& R, int kt, int buf) {
+    unsigned char* S = smem + buf * TSTAGE;
+    const long long rb = row0 + (long long)kt * X3_TK;
+#pragma unroll
+    for (int p = 0; p < G_NP; ++p) {
+      const f32x4 gv = (rb + g_lrow + G_RPP * p < row1) ? R.g[p] : zero4;
+      const Split2 s0 = split2(gv[0], gv[1]), s1 = split2(gv[2], gv[3]);
+      unsigned char* d = S + g_st + p * (G_RPP * GROW);
+      *reinterpret_cast<u32x2*>(d) = u32x2{s0.h, s1.h};
+      *reinterpret_cast<u32x2*>(d + GPLANE) = u32x2{s0.m, s1.m};
+      *reinterpret_cast<u32x2*>(d + 2 * GPLANE) = u32x2{s0.l, s1.l};
+      if (do_bias) bsum += gv;
+    }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      u32x2 H, Mi, L;
-      Split2 s0 = split2(rg[p][0], rg[p][1]), s1 = split2(rg[p][2], rg[p][3]);
-      H = u32x2{s0.h, s1.h}; Mi = u32x2{s0.m, s1.m}; L = u32x2{s0.l, s1.l};
-      unsigned char* d = S + st_off + p * (8 * 256);
-      *reinterpret_cast<u32x2*>(d) = H;
-      *reinterpret_cast<u32x2*>(d + X3_TPLANE) = Mi;
-      *reinterpret_cast<u32x2*>(d + 2 * X3_TPLANE) = L;
-      s0 = split2(rz[p][0], rz[p][1]); s1 = split2(rz[p][2], rz[p][3]);
-      H = u32x2{s0.h, s1.h}; Mi = u32x2{s0.m, s1.m}; L = u32x2{s0.l, s1.l};
-      *reinterpret_cast<u32x2*>(d + 3 * X3_TPLANE) = H;
-      *reinterpret_cast<u32x2*>(d + 4 * X3_TPLANE) = Mi;
-      *reinterpret_cast<u32x2*>(d + 5 * X3_TPLANE) = L;
-      if (do_bias) bsum += rg[p];
+      const f32x4 zv = (rb + z_lrow + 8 * p < row1) ? R.z[p] : zero4;
+      const Split2 s0 = split2(zv[0], zv[1]), s1 = split2(zv[2], zv[3]);
+      unsigned char* d = S + z_st + p * (8 * 256);
+      *reinterpret_cast<u32x2*>(d) = u32x2{s0.h, s1.h};
+      *reinterpret_cast<u32x2*>(d + ZPLANE) = u32x2{s0.m, s1.m};
+      *reinterpret_cast<u32x2*>(d + 2 * ZPLANE) = u32x2{s0.l, s1.l};
     }
   };
 
-  if (nk > 0) {
-    gload(0);
-    lstore(0);
-  }
+  gload(st[0], 0);
+  lstore(st[0], 0, 0);
+  if (PF == 2) gload(st[PF - 1], 1);            // a stage past the end reads the last row again
   __syncthreads();
 
   // transposed fragment reads: lane -> group g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3:
-  // row 8 (g >> 1) + q (+4 for the second read), features 16 (g & 1) + 4 p of the wave's 32-feature block
+  // row 8 (g >> 1) + q (+4 for the second read), features 16 (g & 1) + 4 p of a 32-feature block
   const int q = (lane >> 2) & 3;
-  const int rd_lane = (8 * h + q) * 256 + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
-  int g_rd[2], z_rd[2];
+  const int sub = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+  int g_rd[MT], z_rd[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    g_rd[i] = rd_lane + ((((wave_m * 2 + i) ^ q)) << 6);
-    z_rd[i] = 3 * X3_TPLANE + rd_lane + ((((wave_n * 2 + i) ^ q)) << 6);
-  }
+  for (int i = 0; i < MT; ++i) g_rd[i] = (8 * h + q) * GROW + sub + ((((wave_m * MT + i) ^ q)) << 6);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) z_rd[i] = 3 * GPLANE + (8 * h + q) * 256 + sub + ((((wave_n * 2 + i) ^ q)) << 6);
 
-  for (int kt = 0; kt < nk; ++kt) {
+  auto stage = [&](const int kt, const int u, const bool do_store) {
     const int buf = kt & 1;
-    const bool more = (kt + 1) < nk;
-    if (more) gload(kt + 1);
-    if (wave_live) {
-      const unsigned char* S = smem + buf * X3_TSTAGE;
-      bf16x8 gf[2][3], zf[2][3];
+    gload(st[u % PF], kt + PF);                 // the set that held stage kt (stored one iteration ago)
+    __builtin_amdgcn_sched_barrier(0);          // keep the loads at the top: the compiler would sink them to their use
+    {
+      const unsigned char* S = smem + buf * TSTAGE;
+      bf16x8 gf[MT][3], zf[2][3];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const s16x4 g0 = lds_tr16(S + p * GPLANE + g_rd[i]);
+          const s16x4 g1 = lds_tr16(S + p * GPLANE + g_rd[i] + 4 * GROW);
+          gf[i][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-          const s16x4 g0 = lds_tr16(S + p * X3_TPLANE + g_rd[i]);
-          const s16x4 g1 = lds_tr16(S + p * X3_TPLANE + g_rd[i] + 4 * 256);
-          const s16x4 z0 = lds_tr16(S + p * X3_TPLANE + z_rd[i]);
-          const s16x4 z1 = lds_tr16(S + p * X3_TPLANE + z_rd[i] + 4 * 256);
-          gf[i][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
+          const s16x4 z0 = lds_tr16(S + p * ZPLANE + z_rd[i]);
+          const s16x4 z1 = lds_tr16(S + p * ZPLANE + z_rd[i] + 4 * 256);
           zf[i][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(z0, z1, 0, 1, 2, 3, 4, 5, 6, 7));
         }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           X3_MFMA(gf[i][0], zf[j][2], acc[i][j]);
@@ -457,19 +506,33 @@ __global__ __launch_bounds__(256, 3) void gemmx3_tn_kernel(
           X3_MFMA(gf[i][0], zf[j][0], acc[i][j]);
         }
     }
-    if (more) lstore(buf ^ 1);
+    if (do_store) {
+      lstore(st[(u + 1) % PF], kt + 1, buf ^ 1);
+    }
     __syncthreads();
+  };
+  // every split has an even number of stages except a ragged last one: run pairs, then a single tail stage
+  int kt0 = 0;
+  for (; kt0 + 2 <= nk - 1; kt0 += 2) {
+    stage(kt0, 0, true);
+    stage(kt0 + 1, 1, true);
+  }
+  if (kt0 + 1 < nk) {          // two stages left: nk - 2, nk - 1
+    stage(kt0, 0, true);
+    stage(kt0 + 1, 1, false);
+  } else {                     // one stage left
+    stage(kt0, 0, false);
   }
 
   if (do_bias) {
-    // 8 loader threads (tid & 31 equal) share a feature quad: sum them through LDS (all reads are done)
+    // G_RPP loader threads share a feature quad: sum them through LDS (all fragment reads are done)
     float* red = reinterpret_cast<float*>(smem);
-    *reinterpret_cast<f32x4*>(&red[lrow * 128 + lc4]) = bsum;
+    *reinterpret_cast<f32x4*>(&red[g_lrow * TM + g_lc4]) = bsum;
     __syncthreads();
-    if (tid < 128) {
+    if (tid < TM) {
       float v = 0.f;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v += red[r * 128 + tid];
+      for (int r = 0; r < G_RPP; ++r) v += red[r * TM + tid];
       const int m = m_base + tid;
       if (m < Pm) bslab[(size_t)split * Pm + m] = v;
     }
@@ -477,14 +540,14 @@ __global__ __launch_bounds__(256, 3) void gemmx3_tn_kernel(
   if (!wave_live) return;
   float* out = slab + (size_t)split * Pm * Pn;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n_base + wave_n * 64 + 32 * j + l31;
       if (col < Pn) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = m_base + wave_m * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int m = m_base + wave_m * (32 * MT) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
           if (m < Pm) out[(size_t)m * Pn + col] = acc[i][j][r];
         }
       }
@@ -504,15 +567,30 @@ int gemmx3_tn_splits(int64_t n, int Pm, int Pn, int max_splits) {
 
 hipError_t launch_gemmx3_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n,
                             int Pm, int Pn, int splits, float* slab, float* bslab) {
-  // ragged tiles clamp their loader column to P - 4, which needs whole 128-feature tiles or P >= 128 handled
-  // by the clamp: the kernel requires Pm, Pn multiples of 64 (all padded widths are)
-  if ((Pm & 63) || (Pn & 63) || (ldg & 3) || (ldz & 3) || splits < 1) return hipErrorInvalidValue;
-  const int tiles_m = (Pm + 127) / 128, tiles_n = (Pn + 127) / 128;
+  // all padded widths are multiples of 64; a ragged last tile clamps its loader column inside the row
+  if ((Pm & 63) || (Pn & 63) || (ldg & 3) || (ldz & 3) || splits < 1 || n < 1) return hipErrorInvalidValue;
+  const bool tall = g_x3_tn_tall && (Pm % 256 == 0);
+  const int tiles_m = tall ? Pm / 256 : (Pm + 127) / 128, tiles_n = (Pn + 127) / 128;
   long long chunk = (n + splits - 1) / splits;
-  chunk = (chunk + X3_TK - 1) / X3_TK * X3_TK;
-  if (chunk < X3_TK) chunk = X3_TK;
-  const int splits_pad = (splits + 7) & ~7;
-  hipLaunchKernelGGL(gemmx3_tn_kernel, dim3((unsigned)(tiles_m * tiles_n * splits_pad)), dim3(256), 0, s, G, ldg,
-                     Z, ldz, (long long)n, Pm, Pn, tiles_n, splits, chunk, slab, bslab, tiles_m * tiles_n);
+  chunk = (chunk + 2 * X3_TK - 1) / (2 * X3_TK) * (2 * X3_TK);
+  // no empty split: shrink the count to what the rounded chunk needs
+  const int used = (int)((n + chunk - 1) / chunk);
+  const int splits_pad = (used + 7) & ~7;
+  dim3 grid((unsigned)(tiles_m * tiles_n * splits_pad));
+  // slabs of unused splits must still be defined for the reduce kernels
+  if (used < splits) {
+    hipError_t e = hipMemsetAsync(slab + (size_t)used * Pm * Pn, 0, (size_t)(splits - used) * Pm * Pn * 4, s);
+    if (e != hipSuccess) return e;
+    if (bslab) {
+      e = hipMemsetAsync(bslab + (size_t)used * Pm, 0, (size_t)(splits - used) * Pm * 4, s);
+      if (e != hipSuccess) return e;
+    }
+  }
+  if (tall)
+    hipLaunchKernelGGL(gemmx3_tn_kernel<4>, grid, dim3(256), 0, s, G, ldg, Z, ldz, (long long)n, Pm, Pn, tiles_n,
+                       used, chunk, slab, bslab, tiles_m * tiles_n);
+  else
+    hipLaunchKernelGGL(gemmx3_tn_kernel<2>, grid, dim3(256), 0, s, G, ldg, Z, ldz, (long long)n, Pm, Pn, tiles_n,
+                       used, chunk, slab, bslab, tiles_m * tiles_n);
   return hipGetLastError();
 }
