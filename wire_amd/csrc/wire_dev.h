@@ -168,3 +168,31 @@ WIRE_DEVINL float real_act_bwd(float g, float lin, float out, float w0, float s0
     return lin > 0.f ? g : 0.f;
   }
 }
+
+// lean forms for the split-bf16 GEMM epilogues: hardware transcendentals (v_sin / v_cos / v_exp), same error
+// bounds as gabor_fwd_lean (4e-7 abs for the trigonometric part, 2.4e-7 relative for the exponential)
+template <int ACT>
+WIRE_DEVINL float real_act_fwd_lean(float lin, float w0, float s0) {
+  if (ACT == ACT_SIREN) {
+    float sn, cs;
+    wire_sincos_hw(w0 * lin, sn, cs);
+    return sn;
+  } else if (ACT == ACT_GAUSS) {
+    const float t = s0 * lin;
+    return __builtin_amdgcn_exp2f(-(t * t) * 1.44269502f);
+  } else {
+    return lin > 0.f ? lin : 0.f;
+  }
+}
+template <int ACT>
+WIRE_DEVINL float real_act_bwd_lean(float g, float lin, float out, float w0, float s0) {
+  if (ACT == ACT_SIREN) {
+    float sn, cs;
+    wire_sincos_hw(w0 * lin, sn, cs);
+    return g * w0 * cs;
+  } else if (ACT == ACT_GAUSS) {
+    return g * out * (-2.f * s0 * s0) * lin;
+  } else {
+    return lin > 0.f ? g : 0.f;
+  }
+}

@@ -89,6 +89,61 @@ WIRE_DEVINL void gemm_epilogue(f32x16 (&acc)[MT][WN], const GemmEpiParams& ep, c
       if (done) return;
     }
   }
+  if constexpr (LEAN && EPI == EPI_GABOR_BWD_FIRST) {
+    // first layer: u is recomputed from the coordinates (D <= 3), loads of 8 rows in flight
+    if (m_w + MT * 32 <= M && !ep.wide && ep.D <= 3) {
+      const float m2s2 = -2.f * ep.scale * ep.scale, w0 = ep.omega;
+      const char* __restrict__ out_b = reinterpret_cast<const char*>(ep.i1);
+      const char* __restrict__ crd_b = reinterpret_cast<const char*>(ep.coords);
+      char* __restrict__ gu_b = reinterpret_cast<char*>(ep.o0);
+      const unsigned ld1b = (unsigned)ep.ld1 * 4u, ldub = (unsigned)ep.ldu * 4u, ldcb = (unsigned)ep.D * 4u;
+#pragma unroll
+      for (int jp = 0; jp < WN; jp += 2) {
+        const int c_re = n_w + 32 * jp + l31;
+        const int feat = ((c_re >> 6) << 5) + l31;
+        const bool valid = feat < ep.kvalid;
+        float w[3] = {0.f, 0.f, 0.f};
+        float bb = 0.f;
+        if (valid) {
+          bb = ep.b0[feat];
+          for (int d = 0; d < ep.D; ++d) w[d] = ep.W0[feat * ep.D + d];
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const unsigned row0 = (unsigned)(m_w + 32 * i + 4 * h);
+#pragma unroll
+          for (int rb0 = 0; rb0 < 16; rb0 += 8) {
+            float pr[8], pi[8], x0[8], x1[8], x2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int r = rb0 + j;
+              const unsigned row = row0 + (unsigned)((r & 3) + 8 * (r >> 2));
+              const unsigned off = row * ld1b + (unsigned)c_re * 4u;
+              pr[j] = *reinterpret_cast<const float*>(out_b + off);
+              pi[j] = *reinterpret_cast<const float*>(out_b + off + 128);
+              x0[j] = *reinterpret_cast<const float*>(crd_b + row * ldcb);
+              x1[j] = ep.D > 1 ? *reinterpret_cast<const float*>(crd_b + row * ldcb + 4) : 0.f;
+              x2[j] = ep.D > 2 ? *reinterpret_cast<const float*>(crd_b + row * ldcb + 8) : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int r = rb0 + j;
+              const unsigned row = row0 + (unsigned)((r & 3) + 8 * (r >> 2));
+              float u = __builtin_fmaf(x0[j], w[0], bb);
+              u = __builtin_fmaf(x1[j], w[1], u);
+              u = __builtin_fmaf(x2[j], w[2], u);
+              const float gr = acc[i][jp][r], gi = acc[i][jp + 1][r];
+              const float c_r = __builtin_fmaf(pr[j], gr, pi[j] * gi);
+              const float c_i = __builtin_fmaf(pr[j], gi, -(pi[j] * gr));
+              const float gu = __builtin_fmaf(m2s2 * c_r, u, w0 * c_i);
+              *reinterpret_cast<float*>(gu_b + row * ldub + (unsigned)feat * 4u) = valid ? gu : 0.f;
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
   if constexpr (EPI == EPI_STORE) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -196,7 +251,7 @@ WIRE_DEVINL void gemm_epilogue(f32x16 (&acc)[MT][WN], const GemmEpiParams& ep, c
         for (int r = 0; r < 16; ++r) {
           const int row = m_w + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
           const float lin = acc[i][j][r] + bb;
-          float o = real_act_fwd<ACT>(lin, ep.omega, ep.scale);
+          float o = LEAN ? real_act_fwd_lean<ACT>(lin, ep.omega, ep.scale) : real_act_fwd<ACT>(lin, ep.omega, ep.scale);
           if (!valid) o = 0.f;
           if (row < M) {
             if (ep.o0) ep.o0[(size_t)row * ep.ld0 + col] = lin;
@@ -218,7 +273,8 @@ WIRE_DEVINL void gemm_epilogue(f32x16 (&acc)[MT][WN], const GemmEpiParams& ep, c
             const float lin = ep.i0[(size_t)row * ep.ld0 + col];
             const float out = ep.i1[(size_t)row * ep.ld1 + col];
             ep.o0[(size_t)row * ep.ld0 + col] =
-                real_act_bwd<ACT>(acc[i][j][r], lin, out, ep.omega, ep.scale);
+                LEAN ? real_act_bwd_lean<ACT>(acc[i][j][r], lin, out, ep.omega, ep.scale)
+                     : real_act_bwd<ACT>(acc[i][j][r], lin, out, ep.omega, ep.scale);
           }
         }
     }

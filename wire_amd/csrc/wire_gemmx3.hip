@@ -54,13 +54,20 @@ WIRE_DEVINL unsigned cvt_pk_bf16(float a, float b) {
   const bf16x2 v = {(__bf16)a, (__bf16)b};
   return __builtin_bit_cast(unsigned, v);
 }
+// low half of a packed pair as a float.  Written as an opaque shift: from (H << 16) the compiler would
+// re-derive a second, single-element v_cvt_pk_bf16_f32 (one more VALU op per pair and level).
+WIRE_DEVINL float bf16_lo(unsigned packed) {
+  unsigned r;
+  asm("v_lshlrev_b32 %0, 16, %1" : "=v"(r) : "v"(packed));
+  return __uint_as_float(r);
+}
 struct Split2 { unsigned h, m, l; };
 WIRE_DEVINL Split2 split2(float x0, float x1) {
   Split2 s;
   s.h = cvt_pk_bf16(x0, x1);
-  const float r0 = x0 - __uint_as_float(s.h << 16), r1 = x1 - __uint_as_float(s.h & 0xffff0000u);
+  const float r0 = x0 - bf16_lo(s.h), r1 = x1 - __uint_as_float(s.h & 0xffff0000u);
   s.m = cvt_pk_bf16(r0, r1);
-  const float q0 = r0 - __uint_as_float(s.m << 16), q1 = r1 - __uint_as_float(s.m & 0xffff0000u);
+  const float q0 = r0 - bf16_lo(s.m), q1 = r1 - __uint_as_float(s.m & 0xffff0000u);
   // q has at most 8 significant bits left: the truncating pack is exact
   s.l = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
   return s;
@@ -321,6 +328,7 @@ hipError_t launch_gemmx3_nt(hipStream_t s, int epi, const float* A, int lda, con
       case EPI_STORE: return launchx3_nt_t<EPI_STORE, 4, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
       case EPI_GABOR_FWD: return launchx3_nt_t<EPI_GABOR_FWD, 4, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
       case EPI_GABOR_BWD: return launchx3_nt_t<EPI_GABOR_BWD, 4, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+      case EPI_GABOR_BWD_FIRST: return launchx3_nt_t<EPI_GABOR_BWD_FIRST, 4, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
       default: break;
     }
   }
@@ -409,35 +417,54 @@ __global__ __launch_bounds__(256, (MT > 2 ? 2 : 3)) void gemmx3_tn_kernel(
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (int)((row1 - row0 + X3_TK - 1) / X3_TK);
+  const int nrows = (int)(row1 - row0);
+  const int nk = (nrows + X3_TK - 1) / X3_TK;
+  const int nk_full = nrows / X3_TK;           // stages whose 16 rows all exist
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   constexpr int PF = X3_TN_PF;
   struct Staged { f32x4 g[G_NP], z[2]; };
   Staged st[PF];
-  // rows past the split's end are read from its last row (no branch around the loads) and zeroed when the
-  // stage is split and stored -- not here, where the select would wait for the load
+  // addressing: one wave-uniform row base per stage (scalar registers) + per-thread 32-bit offsets that never
+  // change -> no vector ALU work per stage.  The offsets of the passes are clamped once to the split's last
+  // row, so a stage past the end (prefetch) or the ragged last stage re-reads valid rows.
+  unsigned g_off[G_NP], z_off[2];
+#pragma unroll
+  for (int p = 0; p < G_NP; ++p) g_off[p] = (unsigned)(g_lrow + G_RPP * p) * (unsigned)ldg + (unsigned)gcol;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) z_off[p] = (unsigned)(z_lrow + 8 * p) * (unsigned)ldz + (unsigned)zcol;
+  const float* const g_base = G + (size_t)row0 * ldg;
+  const float* const z_base = Z + (size_t)row0 * ldz;
   auto gload = [&](Staged& R, int kt) {
-    const long long rb = row0 + (long long)kt * X3_TK;
+    // full stages only; anything else points at the last full stage or, when the split has none, at row 0
+    int ks = kt < nk_full ? kt : nk_full - 1;
+    ks = ks < 0 ? 0 : ks;
+    const float* gb = g_base + (size_t)ks * (X3_TK * (size_t)ldg);
+    const float* zb = z_base + (size_t)ks * (X3_TK * (size_t)ldz);
+#pragma unroll
+    for (int p = 0; p < G_NP; ++p) R.g[p] = *reinterpret_cast<const f32x4*>(gb + g_off[p]);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) R.z[p] = *reinterpret_cast<const f32x4*>(zb + z_off[p]);
+  };
+  // the ragged last stage (only the last split of a row count that is not a multiple of 16 has one)
+  auto gload_tail = [&](Staged& R) {
+    const int rb = nk_full * X3_TK;
 #pragma unroll
     for (int p = 0; p < G_NP; ++p) {
-      const long long row = rb + g_lrow + G_RPP * p;
-      const bool ok = row < row1;
-      R.g[p] = *reinterpret_cast<const f32x4*>(G + (size_t)(ok ? row : row1 - 1) * ldg + gcol);
+      const int row = rb + g_lrow + G_RPP * p;
+      R.g[p] = row < nrows ? *reinterpret_cast<const f32x4*>(g_base + (size_t)row * ldg + gcol) : zero4;
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const long long row = rb + z_lrow + 8 * p;
-      const bool ok = row < row1;
-      R.z[p] = *reinterpret_cast<const f32x4*>(Z + (size_t)(ok ? row : row1 - 1) * ldz + zcol);
+      const int row = rb + z_lrow + 8 * p;
+      R.z[p] = row < nrows ? *reinterpret_cast<const f32x4*>(z_base + (size_t)row * ldz + zcol) : zero4;
     }
   };
-  auto lstore = [&](const Staged& R, int kt, int buf) {
+  auto lstore = [&](const Staged& R, int buf) {
     unsigned char* S = smem + buf * TSTAGE;
-    const long long rb = row0 + (long long)kt * X3_TK;
 #pragma unroll
     for (int p = 0; p < G_NP; ++p) {
-      const f32x4 gv = (rb + g_lrow + G_RPP * p < row1) ? R.g[p] : zero4;
+      const f32x4 gv = R.g[p];
       const Split2 s0 = split2(gv[0], gv[1]), s1 = split2(gv[2], gv[3]);
       unsigned char* d = S + g_st + p * (G_RPP * GROW);
       *reinterpret_cast<u32x2*>(d) = u32x2{s0.h, s1.h};
@@ -447,7 +474,7 @@ __global__ __launch_bounds__(256, (MT > 2 ? 2 : 3)) void gemmx3_tn_kernel(
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const f32x4 zv = (rb + z_lrow + 8 * p < row1) ? R.z[p] : zero4;
+      const f32x4 zv = R.z[p];
       const Split2 s0 = split2(zv[0], zv[1]), s1 = split2(zv[2], zv[3]);
       unsigned char* d = S + z_st + p * (8 * 256);
       *reinterpret_cast<u32x2*>(d) = u32x2{s0.h, s1.h};
@@ -456,9 +483,8 @@ __global__ __launch_bounds__(256, (MT > 2 ? 2 : 3)) void gemmx3_tn_kernel(
     }
   };
 
-  gload(st[0], 0);
-  lstore(st[0], 0, 0);
-  if (PF == 2) gload(st[PF - 1], 1);            // a stage past the end reads the last row again
+  if (nk_full > 0) gload(st[0], 0); else gload_tail(st[0]);
+  lstore(st[0], 0);
   __syncthreads();
 
   // transposed fragment reads: lane -> group g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3:
@@ -471,9 +497,12 @@ __global__ __launch_bounds__(256, (MT > 2 ? 2 : 3)) void gemmx3_tn_kernel(
 #pragma unroll
   for (int i = 0; i < 2; ++i) z_rd[i] = 3 * GPLANE + (8 * h + q) * 256 + sub + ((((wave_n * 2 + i) ^ q)) << 6);
 
-  auto stage = [&](const int kt, const int u, const bool do_store) {
+  // stage kt: start the loads of stage kt + 1 (mode 1: a full stage, 2: the ragged tail, 0: nothing),
+  // MFMAs of stage kt from LDS buffer kt & 1, then split + store stage kt + 1 into the other buffer
+  auto stage = [&](const int kt, const int mode) {
     const int buf = kt & 1;
-    gload(st[u % PF], kt + PF);                 // the set that held stage kt (stored one iteration ago)
+    if (mode == 1) gload(st[0], kt + 1);
+    if (mode == 2) gload_tail(st[0]);
     __builtin_amdgcn_sched_barrier(0);          // keep the loads at the top: the compiler would sink them to their use
     {
       const unsigned char* S = smem + buf * TSTAGE;
@@ -506,23 +535,15 @@ __global__ __launch_bounds__(256, (MT > 2 ? 2 : 3)) void gemmx3_tn_kernel(
           X3_MFMA(gf[i][0], zf[j][0], acc[i][j]);
         }
     }
-    if (do_store) {
-      lstore(st[(u + 1) % PF], kt + 1, buf ^ 1);
-    }
+    if (mode != 0) lstore(st[0], buf ^ 1);
     __syncthreads();
   };
-  // every split has an even number of stages except a ragged last one: run pairs, then a single tail stage
-  int kt0 = 0;
-  for (; kt0 + 2 <= nk - 1; kt0 += 2) {
-    stage(kt0, 0, true);
-    stage(kt0 + 1, 1, true);
-  }
-  if (kt0 + 1 < nk) {          // two stages left: nk - 2, nk - 1
-    stage(kt0, 0, true);
-    stage(kt0 + 1, 1, false);
-  } else {                     // one stage left
-    stage(kt0, 0, false);
-  }
+  // full stages 0 .. nk_full - 2 each prefetch the next full stage; then the last full stage (which prefetches
+  // the ragged tail if there is one) and the tail itself
+  int kt = 0;
+  for (; kt + 1 < nk_full; ++kt) stage(kt, 1);
+  if (nk_full > 0) { stage(kt, nk > nk_full ? 2 : 0); ++kt; }
+  if (nk > nk_full) stage(kt, 0);
 
   if (do_bias) {
     // G_RPP loader threads share a feature quad: sum them through LDS (all fragment reads are done)
