@@ -44,6 +44,10 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #ifndef X3_TN_PF
 #define X3_TN_PF 1                   // the same for the weight-gradient kernel (register budget)
 #endif
+#ifndef X3_LOAD_POS
+#define X3_LOAD_POS 2                 // where a stage issues its global loads: 0 top, 1 after the LDS reads, 2 end
+                                     // (2: 5 % faster on 128-row tiles than 0 in a same-box A/B, equal on 256-row tiles)
+#endif
 #ifndef X3_PF
 #define X3_PF 2                      // stages of global prefetch ahead of the MFMAs (1 or 2)
 #endif
@@ -221,11 +225,14 @@ __global__ __launch_bounds__(256, (MT * WN > 4 ? 2 : 3)) void gemmx3_nt_kernel(
     const int buf = kt & 1;
     // the set that held stage kt was stored to LDS one iteration ago: it receives stage kt + PF
 #ifdef WIRE_ABLATE
-    if (do_load && !(ep.ablate & 1)) gload(st[u], kt + PF);
+    const bool ld = do_load && !(ep.ablate & 1);
 #else
-    if (do_load) gload(st[u], kt + PF);
+    const bool ld = do_load;
 #endif
-    __builtin_amdgcn_sched_barrier(0);     // all loads of the stage are issued before its MFMAs
+    if (X3_LOAD_POS == 0) {
+      if (ld) gload(st[u], kt + PF);
+      __builtin_amdgcn_sched_barrier(0);     // all loads of the stage are issued before its MFMAs
+    }
     {
       const unsigned char* S = smem + buf * STAGE;
       bf16x8 af[MT][3], bf[WN][3];
@@ -237,6 +244,11 @@ __global__ __launch_bounds__(256, (MT * WN > 4 ? 2 : 3)) void gemmx3_nt_kernel(
       for (int j = 0; j < WN; ++j)
 #pragma unroll
         for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(S + p * X3_PLANE + b_rd[j]);
+      if (X3_LOAD_POS == 1) {
+        __builtin_amdgcn_sched_barrier(0);   // fragment reads first, then the global loads, then the MFMAs
+        if (ld) gload(st[u], kt + PF);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // small terms first: h*l, l*h, m*m, h*m, m*h, h*h
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -265,6 +277,10 @@ __global__ __launch_bounds__(256, (MT * WN > 4 ? 2 : 3)) void gemmx3_nt_kernel(
         __builtin_amdgcn_sched_group_barrier(0x002, (NPA * 44 + MT * WN * 6 - 1) / (MT * WN * 6) + 1, 0);
         if ((g & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, (NPA * 3 + 3 + 5) / 6, 0);
       }
+    }
+    if (X3_LOAD_POS == 2) {
+      __builtin_amdgcn_sched_barrier(0);     // loads last: behind the MFMAs and the split of the stage
+      if (ld) gload(st[u], kt + PF);
     }
 #ifdef WIRE_ABLATE
     if (!(ep.ablate & 4))
