@@ -139,6 +139,42 @@ def test_fp32_mfma_family_full_configs(name):
         _set_family(L, 1, 1)
 
 
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 127, 129, 255, 257, 4095, 4129])
+def test_ragged_row_counts_against_oracle(n):
+    """Row counts around every boundary of the GEMM kernels (16-row stages and the 32-row split rounding of the
+    weight-gradient kernel, 128- and 256-row tiles of the NT kernel; 4129 > 4096 selects the 256-row tile with
+    a ragged last tile): forward and all gradients of a 2-hidden-layer wire (K = 90: one full and one ragged
+    128-column tile) against the fp64 oracle on the same weights, yardstick = the fp32 oracle's own error."""
+    rec = load_golden("small_wire_d2")
+    m = meta(rec)
+    from wire_amd.modules import models
+    torch.manual_seed(3)
+    model = models.get_INR(nonlin="wire", in_features=2, out_features=3, hidden_features=128, hidden_layers=2,
+                           first_omega_0=m["om1"], hidden_omega_0=m["om"], scale=m["sc"]).to(DEV)
+    rng = np.random.default_rng(n)
+    fake = {k: v for k, v in rec.items() if k.startswith("meta_")}
+    fake["meta_hidden_features"] = np.array(128)
+    fake["meta_L"] = np.array(2)
+    fake["coords"] = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+    fake["target"] = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    P = params_np(model)
+    y, loss, grads = hip_forward_backward(model, fake)
+    y64, _, g64, _ = oracle_run(fake, P, double=True)
+    y32, _, g32, _ = oracle_run(fake, P, double=False)
+    # the yardstick (the reference arithmetic's own fp32 round-off) is a statistic: for a handful of rows take
+    # it from 1024 rows of the same distribution through the same weights
+    big = dict(fake)
+    big["coords"] = rng.uniform(-1, 1, (1024, 2)).astype(np.float32)
+    big["target"] = rng.uniform(0, 1, (1024, 3)).astype(np.float32)
+    yb32, _, gb32, _ = oracle_run(big, P, double=False)
+    yb64, _, gb64, _ = oracle_run(big, P, double=True)
+    err_ref = max(relmax(y32, y64), relmax(yb32, yb64))
+    assert relmax(y, y64) <= 4 * err_ref + 3e-6
+    for k, g in grads.items():
+        ref_err = max(relmax(g32[k], g64[k]), relmax(gb32[k], gb64[k])) + 0.05 * err_ref
+        assert relmax(g, g64[k]) <= 4 * ref_err + 3e-6, k
+
+
 @pytest.mark.parametrize("name", ["small_wire_d2", "small_wire_d3", "small_wire_hi"])
 def test_per_layer_identical_inputs(name):
     """ComplexGaborLayer.forward on the reference's own layer inputs: <= 1e-5."""

@@ -233,6 +233,7 @@ __global__ __launch_bounds__(256, (MT * WN > 4 ? 2 : 3)) void gemmx3_nt_kernel(
       if (ld) gload(st[u], kt + PF);
       __builtin_amdgcn_sched_barrier(0);     // all loads of the stage are issued before its MFMAs
     }
+    if (X3_LOAD_POS == 3 && ld) gload(st[u], kt + PF);   // placed by the group barriers below: spread over the MFMAs
     {
       const unsigned char* S = smem + buf * STAGE;
       bf16x8 af[MT][3], bf[WN][3];
@@ -276,6 +277,8 @@ __global__ __launch_bounds__(256, (MT * WN > 4 ? 2 : 3)) void gemmx3_nt_kernel(
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, (NPA * 44 + MT * WN * 6 - 1) / (MT * WN * 6) + 1, 0);
         if ((g & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, (NPA * 3 + 3 + 5) / 6, 0);
+        if (X3_LOAD_POS == 3 && do_load && (g % 4) == 1 && g / 4 < 2 * NPA + 3)
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
     }
     if (X3_LOAD_POS == 2) {
