@@ -169,7 +169,9 @@ def test_ragged_row_counts_against_oracle(n):
     yb32, _, gb32, _ = oracle_run(big, P, double=False)
     yb64, _, gb64, _ = oracle_run(big, P, double=True)
     err_ref = max(relmax(y32, y64), relmax(yb32, yb64))
-    assert relmax(y, y64) <= 4 * err_ref + 3e-6
+    # ... and so is the scale: one row's outputs can all be small, its round-off is not
+    scale = max(np.abs(y64).max(), np.abs(yb64).max())
+    assert np.abs(y - y64).max() <= (4 * err_ref + 3e-6) * scale
     for k, g in grads.items():
         ref_err = max(relmax(g32[k], g64[k]), relmax(gb32[k], gb64[k])) + 0.05 * err_ref
         assert relmax(g, g64[k]) <= 4 * ref_err + 3e-6, k

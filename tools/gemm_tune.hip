@@ -112,6 +112,7 @@ int main(int argc, char** argv) {
       {"x3 tall gabor_bwd", 4, EPI_GABOR_BWD, 1, 0}, {"x3 tall mfma only", 4, EPI_STORE, 1, 7},
       {"x3 tall noglobal", 4, EPI_STORE, 1, 1},
       {"x3 store no A loads", 4, EPI_STORE, 0, 128}, {"x3 store no B loads", 4, EPI_STORE, 0, 256},
+      {"x3 store nobarrier", 4, EPI_STORE, 0, 4},   {"x3 tall nobarrier", 4, EPI_STORE, 1, 4},
       {"x3 store noglobal", 4, EPI_STORE, 0, 1},    {"x3 store nosplit/lds", 4, EPI_STORE, 0, 2},
       {"x3 store nog+nolds", 4, EPI_STORE, 0, 3},   {"x3 store mfma only", 4, EPI_STORE, 0, 7},
   };

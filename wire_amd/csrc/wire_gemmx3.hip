@@ -342,6 +342,7 @@ hipError_t launch_gemmx3_nt(hipStream_t s, int epi, const float* A, int lda, con
   GemmEpiParams ep = ep_in;
   if ((epi == EPI_GABOR_FWD || epi == EPI_GABOR_BWD) && ep.ld0 != ep.ld1) ep.wide = 1;
   if ((double)M * (double)(ep.ld1 > ep.ld0 ? ep.ld1 : ep.ld0) * 4.0 >= 4294967296.0) ep.wide = 1;
+  // (256-row tiles for wire2d and the real nets were measured 5 % SLOWER on their steps: they stay on 128 rows)
   if (g_x3_tall && M >= 4096) {
     switch (epi) {
       case EPI_STORE: return launchx3_nt_t<EPI_STORE, 4, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
