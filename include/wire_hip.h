@@ -182,6 +182,14 @@ int wire_mse_grad(void* stream, const float* y, const float* target,
                   const int64_t* idx, int64_t first, int64_t n, int O,
                   float weight, float* g_y, float* loss_out, float* rec,
                   float* partial);
+/* Super-resolution loss of wire_SISR.py:151-161: rec = torch.nn.AvgPool2d(scale) of the full-grid
+ * reconstruction y [H*W][O] (row n = i*W + j), loss = mean((gt_lr - rec)^2) over [H/scale][W/scale][O]
+ * (floor: ragged borders are dropped and receive zero gradient).  Writes loss_out[0], g_y = dL/dy [H*W][O]
+ * and, if rec_lr != NULL, the pooled image.  partial: >= 1024 floats of scratch.                       */
+int wire_avgpool_mse_grad(void* stream, const float* y, int H, int W, int O, int scale,
+                          const float* gt_lr, float* g_y, float* rec_lr, float* loss_out,
+                          float* partial);
+
 /* torch.optim.Adam single step over a flat fp32 buffer (complex tensors as
  * real pairs; wire_image_denoise.py:123-125).  step is 1-based.            */
 int wire_adam_step_flat(void* stream, float* param, const float* grad,

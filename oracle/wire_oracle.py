@@ -353,6 +353,23 @@ def mse_loss_and_grad(y: np.ndarray, target: np.ndarray):
     return loss, (2.0 / diff.size) * diff
 
 
+def avgpool_mse_loss_and_grad(y: np.ndarray, H: int, W: int, scale: int, gt_lr: np.ndarray):
+    """Super-resolution loss of wire_SISR.py:151-161: ``rec = torch.nn.AvgPool2d(scale)(rec_hr)`` with
+    rec_hr = y reshaped [H, W, O] (row n = i*W + j), ``loss = ((gt_lr - rec)**2).mean()`` over
+    [H//scale, W//scale, O] (ceil_mode=False: ragged borders are dropped), and dL/dy [H*W, O].
+    Returns (loss, g_y, rec) with rec [H2*W2, O]."""
+    O = y.shape[-1]
+    H2, W2 = H // scale, W // scale
+    img = y.reshape(H, W, O)[:H2 * scale, :W2 * scale]
+    rec = img.reshape(H2, scale, W2, scale, O).mean(axis=(1, 3))
+    diff = rec - gt_lr.reshape(H2, W2, O)
+    loss = np.mean(np.square(diff))
+    g_rec = (2.0 / diff.size) * diff
+    g = np.zeros((H, W, O), dtype=y.dtype)
+    g[:H2 * scale, :W2 * scale] = np.repeat(np.repeat(g_rec, scale, axis=0), scale, axis=1) / (scale * scale)
+    return loss, g.reshape(H * W, O), rec.reshape(H2 * W2, O)
+
+
 def as_real_pairs(a: np.ndarray) -> np.ndarray:
     """torch.view_as_real equivalent (copy)."""
     if np.iscomplexobj(a):

@@ -558,3 +558,53 @@ def test_real_layers_identical_inputs_and_backward(name):
     assert relmax(z.grad.cpu().numpy().reshape(lin.shape[0], -1), gl @ W) < 2e-5
     assert relmax(model.net[1].linear.weight.grad.cpu().numpy(), gl.T @ z64) < 2e-5
     assert relmax(model.net[1].linear.bias.grad.cpu().numpy(), gl.sum(0)) < 2e-5
+
+
+@pytest.mark.parametrize("H,W,scale", [(24, 24, 3), (26, 21, 4)])
+def test_super_resolution_step_matches_oracle(H, W, scale):
+    """wire_SISR.py:151-178 shape: full high-resolution grid -> AvgPool2d(scale) -> MSE against the low-resolution
+    image -> backward.  The device kernel alone against the oracle's restatement (which test_oracle_golden pins to
+    torch.nn.AvgPool2d), then every parameter gradient of FusedTrainer.step_downsampled against the fp64 oracle."""
+    from wire_amd import _lib
+    from wire_amd.trainer import FusedTrainer
+    from wire_amd.modules import models
+    import ctypes as C
+    L = _lib.lib()
+    rng = np.random.default_rng(H + W)
+    O, H2, W2 = 3, H // scale, W // scale
+    # --- the operator alone
+    y = rng.standard_normal((H * W, O)).astype(np.float32)
+    gt = rng.standard_normal((H2 * W2, O)).astype(np.float32)
+    l64, g64, r64 = wo.avgpool_mse_loss_and_grad(y.astype(np.float64), H, W, scale, gt.astype(np.float64))
+    yt, gtt = torch.tensor(y, device=DEV), torch.tensor(gt, device=DEV)
+    gy = torch.full((H * W, O), 7.0, device=DEV)
+    rec = torch.empty(H2 * W2, O, device=DEV)
+    loss = torch.zeros(1, device=DEV)
+    part = torch.empty(4096, device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.wire_avgpool_mse_grad(stream, yt.data_ptr(), H, W, O, scale, gtt.data_ptr(), gy.data_ptr(),
+                                       rec.data_ptr(), loss.data_ptr(), part.data_ptr()))
+    torch.cuda.synchronize()
+    assert abs(float(loss) - l64) <= 1e-5 * l64
+    np.testing.assert_allclose(gy.cpu().numpy(), g64, rtol=0, atol=1e-6 * np.abs(g64).max() + 1e-12)
+    np.testing.assert_allclose(rec.cpu().numpy(), r64, rtol=0, atol=2e-6)
+    assert L.wire_avgpool_mse_grad(stream, yt.data_ptr(), H, W, O, H + 1, gtt.data_ptr(), gy.data_ptr(),
+                                   None, loss.data_ptr(), part.data_ptr()) < 0      # scale > H: refused
+    # --- the whole step (lr = 0: parameters stay put)
+    torch.manual_seed(0)
+    model = models.get_INR(nonlin="wire", in_features=2, out_features=O, hidden_features=128, hidden_layers=2,
+                           first_omega_0=7.0, hidden_omega_0=7.0, scale=6.0).to(DEV)
+    tr = FusedTrainer(model, (H, W), torch.zeros(H * W, O), lr=0.0)
+    lossd = tr.step_downsampled(gtt, scale)
+    torch.cuda.synchronize()
+    P64 = wo.cast_params(params_np(model), True)
+    coords = wo.image_coords(H, W).astype(np.float64)
+    y64, cache = wo.wire_forward(P64, coords, 2, 7.0, 7.0, 6.0, keep=True)
+    l64, gy64, _ = wo.avgpool_mse_loss_and_grad(y64, H, W, scale, gt.astype(np.float64))
+    g64 = wo.wire_backward(P64, cache, gy64, 2, 7.0, 7.0, 6.0)
+    assert abs(float(lossd.item()) - l64) <= 2e-5 * l64
+    flat = tr.flat_grad.cpu().numpy()
+    names = [k for k in model.state_dict().keys() if "omega_0" not in k and "scale_0" not in k]
+    for name, off, t in zip(names, tr.offsets, model.param_tensors()):
+        g = wo.as_real_pairs(g64[name]).astype(np.float64).ravel()
+        assert np.abs(flat[off:off + g.size] - g).max() <= 5e-5 * np.abs(g).max() + 1e-10, name

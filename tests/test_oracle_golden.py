@@ -137,3 +137,23 @@ def test_misc_known_answers():
     assert int(rec["nparams_2x300"]) == 91587
     assert wo.wire_flops_per_sample(256, 4, 2, 3) == 6302720
     assert wo.wire_flops_per_sample(181, 4, 2, 3) == 3153020
+
+
+@pytest.mark.parametrize("H,W,scale", [(12, 12, 3), (13, 10, 4), (8, 9, 1)])
+def test_avgpool_loss_restatement_matches_torch(H, W, scale):
+    """The super-resolution loss (wire_SISR.py:151-161) is torch.nn.AvgPool2d + MSE: the oracle's numpy
+    restatement against that operator and its autograd, fp64."""
+    import torch
+    rng = np.random.default_rng(H * 100 + W)
+    O = 3
+    y = rng.standard_normal((H * W, O))
+    H2, W2 = H // scale, W // scale
+    gt = rng.standard_normal((H2 * W2, O))
+    loss, g, rec = wo.avgpool_mse_loss_and_grad(y, H, W, scale, gt)
+    yt = torch.tensor(y, requires_grad=True)
+    pooled = torch.nn.AvgPool2d(scale)(yt.reshape(H, W, O).permute(2, 0, 1)[None, ...])
+    lt = ((torch.tensor(gt)[None, ...] - pooled.reshape(1, O, -1).permute(0, 2, 1)) ** 2).mean()
+    lt.backward()
+    assert abs(loss - float(lt.detach())) <= 1e-14 * max(1.0, abs(float(lt.detach())))
+    np.testing.assert_allclose(g, yt.grad.numpy(), rtol=0, atol=1e-15)
+    np.testing.assert_allclose(rec, pooled.reshape(O, -1).T.detach().numpy(), rtol=0, atol=1e-14)

@@ -610,6 +610,15 @@ extern "C" int wire_mse_grad(void* stream, const float* y, const float* target, 
                          rec, partial));
   return WIRE_OK;
 }
+extern "C" int wire_avgpool_mse_grad(void* stream, const float* y, int H, int W, int O, int scale,
+                                     const float* gt_lr, float* g_y, float* rec_lr, float* loss_out,
+                                     float* partial) {
+  if (H < 1 || W < 1 || O < 1 || scale < 1 || scale > H || scale > W || !y || !gt_lr || !g_y || !loss_out || !partial)
+    return fail(WIRE_ERR_ARG, "bad argument to wire_avgpool_mse_grad");
+  ProfScope ps((hipStream_t)stream, 3, 0);
+  HIPCHK(launch_avgpool_mse_grad((hipStream_t)stream, y, H, W, O, scale, gt_lr, g_y, rec_lr, loss_out, partial));
+  return WIRE_OK;
+}
 extern "C" int wire_adam_step_flat(void* stream, float* param, const float* grad, float* exp_avg,
                                    float* exp_avg_sq, int64_t count, float lr, float beta1,
                                    float beta2, float eps, int64_t step) {

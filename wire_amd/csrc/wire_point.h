@@ -86,6 +86,11 @@ hipError_t launch_coords(hipStream_t s, const int64_t* idx, int64_t first, int64
 hipError_t launch_mse_grad(hipStream_t s, const float* y, const float* target, const int64_t* idx,
                            int64_t first, int64_t n, int O, float weight, float* g_y,
                            float* loss_out, float* rec, float* partial);
+// super-resolution loss: AvgPool2d(scale) of the [H W][O] reconstruction against gt_lr [H2 W2][O]
+// (wire_SISR.py:151-161): loss, dL/dy (g_y [H W][O]), optionally the pooled image; partial >= 1024 floats
+hipError_t launch_avgpool_mse_grad(hipStream_t s, const float* y, int H, int W, int O, int scale,
+                                   const float* gt_lr, float* g_y, float* rec_lr, float* loss_out,
+                                   float* partial);
 hipError_t launch_adam(hipStream_t s, float* p, const float* g, float* m, float* v, int64_t count,
                        float step_size, float beta1, float beta2, float eps, float inv_sqrt_bc2);
 

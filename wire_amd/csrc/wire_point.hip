@@ -1037,6 +1037,68 @@ hipError_t launch_mse_grad(hipStream_t s, const float* y, const float* target, c
   return hipGetLastError();
 }
 
+// ===========================================================================
+// super-resolution loss (wire_SISR.py:151-161): rec = AvgPool2d(scale)(rec_hr as [O][H][W]),
+// loss = mean((gt_lr - rec)^2) over H2 W2 O, H2 = H / scale, W2 = W / scale (floor: AvgPool2d's default
+// ceil_mode = False drops ragged borders).  One thread per pooled element; it also scatters
+// dL/d rec_hr = 2 (rec - gt_lr) / (H2 W2 O scale^2) to its scale x scale window.  y, g_y: [H W][O].
+// ===========================================================================
+__global__ __launch_bounds__(256) void avgpool_mse_grad_kernel(const float* __restrict__ y, int H, int W, int O,
+                                                               int sc, int H2, int W2,
+                                                               const float* __restrict__ gt_lr, float gscale,
+                                                               float* __restrict__ g_y,
+                                                               float* __restrict__ rec_lr,
+                                                               float* __restrict__ partial) {
+  __shared__ float red[256];
+  const long long total = (long long)H2 * W2 * O;
+  const float inv = 1.f / (float)(sc * sc);
+  float acc = 0.f;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long pix = e / O;
+    const int o = (int)(e - pix * O);
+    const int pi = (int)(pix / W2), pj = (int)(pix - (long long)pi * W2);
+    const float* src = y + ((size_t)(pi * sc) * W + (size_t)pj * sc) * O + o;
+    float sum = 0.f;
+    for (int a = 0; a < sc; ++a)
+      for (int b = 0; b < sc; ++b) sum += src[((size_t)a * W + b) * O];
+    const float pool = sum * inv;
+    const float d = pool - gt_lr[e];
+    if (rec_lr) rec_lr[e] = pool;
+    const float g = gscale * d;
+    float* dst = g_y + ((size_t)(pi * sc) * W + (size_t)pj * sc) * O + o;
+    for (int a = 0; a < sc; ++a)
+      for (int b = 0; b < sc; ++b) dst[((size_t)a * W + b) * O] = g;
+    acc = __builtin_fmaf(d, d, acc);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int sft = 128; sft >= 1; sft >>= 1) {
+    if (threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+hipError_t launch_avgpool_mse_grad(hipStream_t s, const float* y, int H, int W, int O, int scale,
+                                   const float* gt_lr, float* g_y, float* rec_lr, float* loss_out,
+                                   float* partial) {
+  const int H2 = H / scale, W2 = W / scale;
+  if (H2 < 1 || W2 < 1) return hipErrorInvalidValue;
+  // ragged borders receive no gradient
+  if (H2 * scale != H || W2 * scale != W) {
+    hipError_t e = hipMemsetAsync(g_y, 0, (size_t)H * W * O * sizeof(float), s);
+    if (e != hipSuccess) return e;
+  }
+  const long long total = (long long)H2 * W2 * O;
+  unsigned nb = cdiv(total, 256);
+  if (nb > MSE_BLOCKS) nb = MSE_BLOCKS;
+  const double invn = 1.0 / (double)total;
+  hipLaunchKernelGGL(avgpool_mse_grad_kernel, dim3(nb), dim3(256), 0, s, y, H, W, O, scale, H2, W2, gt_lr,
+                     (float)(2.0 * invn / ((double)scale * scale)), g_y, rec_lr, partial);
+  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, s, partial, (int)nb, (float)invn, loss_out);
+  return hipGetLastError();
+}
+
 // torch.optim.Adam (_single_tensor_adam): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) m/denom
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,

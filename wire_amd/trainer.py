@@ -200,6 +200,54 @@ class FusedTrainer:
         self.loss = gsum[self.count:self.count + 1].clone()   # the buffer is reused next step
         return self.loss
 
+    # ------------------------------------------------------------------ super-resolution step
+    def step_downsampled(self, gt_lr: torch.Tensor, scale: int,
+                         rec_lr: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One optimizer step of the super-resolution loop (wire_SISR.py:151-178): the model is
+        evaluated on the WHOLE high-resolution grid in raster order, ``torch.nn.AvgPool2d(scale)``
+        brings the reconstruction to the resolution of ``gt_lr`` ([H//scale * W//scale, O], device
+        float32), loss = mean squared error there; backward through the pooling and the network,
+        Adam.  The high-resolution reconstruction of this step stays in ``self.y`` ([H*W, O]).
+        2-D grids, single process (a pooled window must not straddle two shards)."""
+        if self.tz is not None or len(self.grid) != 2:
+            raise ValueError("step_downsampled needs a 2-D grid")
+        if self.world != 1:
+            raise NotImplementedError("step_downsampled is single-process")
+        H, W = int(self.grid[0]), int(self.grid[1])
+        scale = int(scale)
+        if scale < 1 or scale > min(H, W):
+            raise ValueError(f"scale {scale} outside 1..min(H, W)")
+        H2, W2 = H // scale, W // scale
+        gt = gt_lr.detach()
+        if not gt.is_cuda or gt.dtype != torch.float32 or gt.numel() != H2 * W2 * self.O:
+            raise ValueError(f"gt_lr must be a CUDA float32 tensor of {H2 * W2} x {self.O} elements")
+        gt = gt.contiguous()
+        if rec_lr is not None and (not rec_lr.is_cuda or rec_lr.dtype != torch.float32
+                                   or rec_lr.numel() != gt.numel() or not rec_lr.is_contiguous()):
+            raise ValueError("rec_lr must be a contiguous CUDA float32 tensor shaped like gt_lr")
+        L, d = self.L, C.byref(self.desc)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        n = H * W
+        self._reserve(n)
+        g = self.gbuf[0]
+        _lib.check(L.wire_pack_params(stream, d, self.param_ptrs, self.packed.data_ptr()), "pack")
+        _lib.check(L.wire_coords_from_index(stream, None, 0, n, self.tx.data_ptr(), W, self.ty.data_ptr(), H,
+                                            None, 1, self.coords.data_ptr()), "coords")
+        _lib.check(L.wire_mlp_fwd(stream, d, self.packed.data_ptr(), self.coords.data_ptr(), n,
+                                  self.y.data_ptr(), self.act.data_ptr(), self.act_bytes, 1), "fwd")
+        _lib.check(L.wire_avgpool_mse_grad(stream, self.y.data_ptr(), H, W, self.O, scale, gt.data_ptr(),
+                                           self.gy.data_ptr(), rec_lr.data_ptr() if rec_lr is not None else None,
+                                           g.data_ptr() + 4 * self.count, self.partial.data_ptr()), "avgpool_mse_grad")
+        _lib.check(L.wire_mlp_bwd(stream, d, self.packed.data_ptr(), self.coords.data_ptr(), n,
+                                  self.gy.data_ptr(), self.act.data_ptr(), self.act_bytes,
+                                  self.scratch.data_ptr(), self.scr_bytes, self.grad_ptrs[0]), "bwd")
+        self.t += 1
+        _lib.check(L.wire_adam_step_flat(stream, self.flat.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(),
+                                         self.exp_avg_sq.data_ptr(), self.count, self.current_lr(),
+                                         self.betas[0], self.betas[1], self.eps, self.t), "adam")
+        self.loss = g[self.count:self.count + 1].clone()
+        return self.loss
+
     @property
     def flat_grad(self) -> torch.Tensor:
         return self.gbuf[0][:self.count]
