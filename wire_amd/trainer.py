@@ -22,6 +22,7 @@ backward of micro-shard i+1.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -100,7 +101,11 @@ class FusedTrainer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
-        self.reducers = [FlatGradAllReducer(g, group) for g in self.gbuf]
+        # one micro-shard: nothing to overlap the collective with, so it is issued from the compute stream
+        # (two cross-stream hand-offs fewer per step); several: a side stream overlaps it with the next shard
+        side = self.micro > 1 and os.environ.get("WIRE_DP_SIDE_STREAM", "1") != "0" or \
+            os.environ.get("WIRE_DP_SIDE_STREAM", "") == "1"
+        self.reducers = [FlatGradAllReducer(g, group, use_side_stream=side) for g in self.gbuf]
         self._cap = 0
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
 
