@@ -28,6 +28,17 @@ __global__ void fill_kernel(float* p, size_t n, unsigned seed, float scale) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   p[i] = ((x >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale;
 }
+__global__ void add_kernel(float* p, size_t n, float v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] += v;
+}
+__global__ void zero_some_kernel(float* p, size_t n, int pct) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned x = (unsigned)(i * 2246822519u) ^ 0x9e3779b9u;
+  x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12; x *= 0x297a2d39u; x ^= x >> 15;
+  if ((int)(x % 100u) < pct) p[i] = 0.f;
+}
 static float* dalloc(size_t n, unsigned seed, float scale) {
   float* p; CK(hipMalloc(&p, n * sizeof(float)));
   fill_kernel<<<(unsigned)((n + 255) / 256), 256>>>(p, n, seed, scale);
@@ -39,8 +50,19 @@ int main(int argc, char** argv) {
   const int P = argc > 2 ? atoi(argv[2]) : 512;
   const int rounds = argc > 3 ? atoi(argv[3]) : 5;
   const int Kp = P / 2;
-  float* A = dalloc((size_t)N * P, 1, 1.0f);
-  float* Bt = dalloc((size_t)P * P, 2, 0.06f);
+  // argv[5] = 1: constant operands (every element 0.75 / 0.0625: the m and l planes are zero, nothing toggles) --
+  // same instruction stream, a fraction of the switching power: separates stalls from the power limit
+  const bool constant = argc > 5 && atoi(argv[5]) == 1;
+  float* A = dalloc((size_t)N * P, 1, constant ? 0.f : 1.0f);
+  float* Bt = dalloc((size_t)P * P, 2, constant ? 0.f : 0.06f);
+  // argv[6] = percentage of the activation elements set to exactly 0 (pseudo-random positions): do zero
+  // operands cost the matrix pipe less power?  (WIRE activations at s0 = 30 are mostly < 1e-30.)
+  const int zero_pct = argc > 6 ? atoi(argv[6]) : 0;
+  if (zero_pct > 0) zero_some_kernel<<<(unsigned)(((size_t)N * P + 255) / 256), 256>>>(A, (size_t)N * P, zero_pct);
+  if (constant) {
+    add_kernel<<<(unsigned)(((size_t)N * P + 255) / 256), 256>>>(A, (size_t)N * P, 0.75f);
+    add_kernel<<<(unsigned)(((size_t)P * P + 255) / 256), 256>>>(Bt, (size_t)P * P, 0.0625f);
+  }
   float* bias = dalloc(P, 3, 0.06f);
   float* lin = dalloc((size_t)N * P, 4, 0.5f);
   float* out = dalloc((size_t)N * P, 5, 1.0f);
