@@ -490,7 +490,9 @@ __global__ __launch_bounds__(256, (MT > 2 ? 2 : 3)) void gemmx3_tn_kernel(
       *reinterpret_cast<u32x2*>(d) = u32x2{s0.h, s1.h};
       *reinterpret_cast<u32x2*>(d + GPLANE) = u32x2{s0.m, s1.m};
       *reinterpret_cast<u32x2*>(d + 2 * GPLANE) = u32x2{s0.l, s1.l};
-      if (do_bias) bsum += gv;
+      if (do_bias) {   // scalar adds: a packed v_pk_add_f32 costs the MFMA stream more than two v_add_f32
+        bsum[0] += gv[0]; bsum[1] += gv[1]; bsum[2] += gv[2]; bsum[3] += gv[3];
+      }
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
