@@ -597,9 +597,18 @@ __global__ __launch_bounds__(256, (MT > 2 ? 2 : 3)) void gemmx3_tn_kernel(
     }
 }
 
+// Row splits of the weight gradient: tiles x splits workgroups should fill the 256 CUs of an MI355X with the
+// SAME number of resident workgroups each (3, else 2, else 1) -- e.g. K = 181 (9 tiles): 56 splits = 504
+// workgroups = 2 per CU, where 64 splits (576 workgroups) would leave a quarter of the CUs with 3 and the
+// rest with 2, and the launch waits for the loaded ones.
 int gemmx3_tn_splits(int64_t n, int Pm, int Pn, int max_splits) {
   const int tiles = ((Pm + 127) / 128) * ((Pn + 127) / 128);
-  int s = (768 + tiles - 1) / tiles;          // ~3 workgroups per CU
+  int s = 0;
+  for (int w = 3; w >= 1 && s == 0; --w) {
+    const int c = (256 * w) / tiles;
+    if (c >= 1 && c <= max_splits) s = c;
+  }
+  if (s == 0) s = tiles > 768 ? 1 : max_splits;   // the tiles alone fill the chip / fewer tiles than the cap allows
   int64_t by_rows = (n + 255) / 256;          // at least 256 rows per split
   if (by_rows < 1) by_rows = 1;
   if (s > by_rows) s = (int)by_rows;
