@@ -216,11 +216,21 @@ def main():
         avg_ms = ms[klass] / max(1, cnt[klass])
         achieved = alg_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic = None
+        hbm = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = (tj.get("split_bf16", {}) if split else tj.get("fp32_mfma", tj)).get(str(klass))
+                fam = tj.get("split_bf16", {}) if split else tj.get("fp32_mfma", tj)
+                traffic = fam.get(str(klass))
+                # HBM rate of the GEMMs from the PMC byte counts per launch (committed profile) and the launch
+                # times measured in THIS run: evidence of fusion quality, not the bound
+                if all(str(i) in fam and cnt[i] > 0 for i in range(3)) and args.micro_shards == 1 and world == 1:
+                    gb = sum(fam[str(i)] * cnt[i] for i in range(3))
+                    gms = sum(ms[i] for i in range(3))
+                    hbm = {"gemm_bytes_per_step": gb / args.steps, "gemm_tb_per_s": gb / (gms * 1e-3) / 1e12,
+                           "frac_of_8_tb_per_s": gb / (gms * 1e-3) / 8e12,
+                           "source": "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE) x launches / GEMM time of this run"}
             except Exception:
                 traffic = None
         out = {
@@ -247,6 +257,8 @@ def main():
             "kernel_ms_per_step": {names[i]: ms[i] / args.steps for i in range(4)},
             "final_loss": final_loss,
         }
+        if hbm is not None:
+            out["hbm"] = hbm
         if world == 1 and not args.no_extras:
             out["extras"] = extras(dev, lib)
         if world == 1 and not args.no_cpu_baseline:
