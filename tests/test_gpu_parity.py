@@ -8,12 +8,14 @@ error grows with omega0 and depth.  Whole-network checks therefore require
 and per-layer checks on identical inputs require 1e-5 relative to the layer max.
 """
 import ctypes as C
+import os
+import sys
 
 import numpy as np
 import pytest
 import torch
 
-from _util import FULL, SMALL, build_model, load_golden, meta, oracle_run, params_np, relmax
+from _util import FULL, ROOT, SMALL, build_model, load_golden, meta, oracle_run, params_np, relmax
 from oracle import wire_oracle as wo
 
 pytestmark = pytest.mark.gpu
@@ -608,3 +610,13 @@ def test_super_resolution_step_matches_oracle(H, W, scale):
     for name, off, t in zip(names, tr.offsets, model.param_tensors()):
         g = wo.as_real_pairs(g64[name]).astype(np.float64).ravel()
         assert np.abs(flat[off:off + g.size] - g).max() <= 5e-5 * np.abs(g).max() + 1e-10, name
+
+
+def test_random_shapes_against_oracle():
+    """tools/fuzz_shapes.py: wire nets of random width / depth / D / O on random row counts, forward and all
+    gradients within 4 x the fp32 reference arithmetic's own error against fp64 (60 cases ran clean by hand;
+    16 here)."""
+    import importlib
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    fz = importlib.import_module("fuzz_shapes")
+    assert fz.main(16, 11) < 4.5
