@@ -196,3 +196,15 @@ WIRE_DEVINL float real_act_bwd_lean(float g, float lin, float out, float w0, flo
     return lin > 0.f ? g : 0.f;
   }
 }
+
+// 2-D Gabor, lean form (hardware v_exp / v_sin / v_cos, as gabor_fwd_lean)
+WIRE_DEVINL void gabor2d_fwd_lean(float u, float v, float p, float q, float w0, float s0, float& o_re,
+                                  float& o_im) {
+  const float arg = __builtin_fmaf(u, u, v * v) + __builtin_fmaf(p, p, q * q);
+  const float t = __builtin_fmaf(-(s0 * s0) * 1.44269502f, arg, -(w0 * 1.44269502f) * v);   // log2 of the envelope
+  const float e = __builtin_amdgcn_exp2f(t);
+  float sn, cs;
+  wire_sincos_hw(w0 * u, sn, cs);
+  o_re = e * cs;
+  o_im = e * sn;
+}

@@ -174,7 +174,8 @@ WIRE_DEVINL void gemm_epilogue(f32x16 (&acc)[MT][WN], const GemmEpiParams& ep, c
           const float u = acc[i][jp][r] + b_re;
           const float v = acc[i][jp + 1][r] + b_im;
           float o_re, o_im;
-          gabor_fwd(u, v, ep.omega, ep.scale, o_re, o_im);
+          if (LEAN) gabor_fwd_lean(u, v, ep.omega, ep.omega * 1.44269502f, -(ep.scale * ep.scale) * 1.44269502f, o_re, o_im);
+          else gabor_fwd(u, v, ep.omega, ep.scale, o_re, o_im);
           if (!valid) { o_re = 0.f; o_im = 0.f; }
           if (row < M) {
             if (ep.o0) {
@@ -295,7 +296,8 @@ WIRE_DEVINL void gemm_epilogue(f32x16 (&acc)[MT][WN], const GemmEpiParams& ep, c
         const float u = acc[i][0][r] + b_u, v = acc[i][1][r] + b_v;
         const float p = acc[i][2][r] + b_p, q = acc[i][3][r] + b_q;
         float o_re, o_im;
-        gabor2d_fwd(u, v, p, q, ep.omega, ep.scale, o_re, o_im);
+        if (LEAN) gabor2d_fwd_lean(u, v, p, q, ep.omega, ep.scale, o_re, o_im);
+        else gabor2d_fwd(u, v, p, q, ep.omega, ep.scale, o_re, o_im);
         if (!valid) { o_re = 0.f; o_im = 0.f; }
         if (row < M) {
           if (ep.o0) {
