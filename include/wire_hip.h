@@ -208,6 +208,20 @@ int wire_adam_step_flat(void* stream, float* param, const float* grad,
 int wire_eval_metric(void* stream, int mode, const float* rec, const float* gt,
                      int64_t count, float thres, float* out2, float* partial);
 
+/* ---- ComplexGaborLayer2D (modules/wire2d.py:21-67) on native tensors ---------------------
+ * act = exp(j w0 lin) exp(-s0^2 (|lin|^2 + |sy|^2)),  lin = x W^T + b,  sy = x V^T + c (scale_orth).
+ * Same conventions as wire_gabor_fwd / wire_gabor_bwd: x, act, g_act, g_x complex64 [n][features]
+ * (is_first: x real float32 [n][in <= 4], W, b, V, c real, g_x unused); W, V [out][in], b, c [out];
+ * the backward recomputes the forward from x.  g_x may be NULL.                                   */
+int64_t wire_layer2d_ws_bytes(int64_t n, int in_features, int out_features);
+int wire_gabor2d_fwd(void* stream, const void* x, const void* W, const void* b, const void* V,
+                     const void* c, float omega0, float scale0, int64_t n, int in_features,
+                     int out_features, int is_first, void* act_out, void* ws, int64_t ws_bytes);
+int wire_gabor2d_bwd(void* stream, const void* g_act, const void* x, const void* W, const void* b,
+                     const void* V, const void* c, float omega0, float scale0, int64_t n,
+                     int in_features, int out_features, int is_first, void* g_x, void* g_W, void* g_b,
+                     void* g_V, void* g_c, void* ws, int64_t ws_bytes);
+
 /* ---- layout helpers ---------------------------------------------------- */
 int wire_blocked_width(int K);   /* P = roundup(2K, 64) */
 int wire_c64_to_blocked(void* stream, const void* src, int64_t n, int K, float* dst);

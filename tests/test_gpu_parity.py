@@ -620,3 +620,70 @@ def test_random_shapes_against_oracle():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     fz = importlib.import_module("fuzz_shapes")
     assert fz.main(16, 11) < 4.5
+
+
+def test_wire2d_per_layer_identical_inputs():
+    """ComplexGaborLayer2D.forward (modules/wire2d.py:56-67) stand-alone, on the reference's own layer inputs
+    (what modules/utils.py:246-252 does for visualisation): <= 1e-5 per layer."""
+    rec = load_golden("small_wire2d")
+    model = load_small(rec, build_model(rec))
+    L = meta(rec)["L"]
+    x = torch.tensor(rec["coords"], device=DEV)
+    for i in range(L + 1):
+        out = model.net[i](x)
+        torch.cuda.synchronize()
+        assert out.dtype == torch.complex64
+        assert relmax(out.detach().cpu().numpy(), rec[f"act{i}"]) <= 1e-5, f"layer {i}"
+        x = torch.tensor(rec[f"act{i}"], device=DEV)
+
+
+@pytest.mark.parametrize("is_first", [False, True])
+def test_wire2d_layer_backward_matches_autograd(is_first):
+    """Stand-alone ComplexGaborLayer2D: every gradient (input, both Linears) against eager fp64 autograd of the
+    oracle's restatement (oracle/torch_ref.gabor2d), yardstick = the same in fp32."""
+    from oracle import torch_ref
+    from wire_amd.modules.wire2d import ComplexGaborLayer2D
+    import torch.nn.functional as F
+    torch.manual_seed(5)
+    n, fin, fout = 300, (2 if is_first else 70), 90
+    om, sc = 10.0, 10.0
+    layer = ComplexGaborLayer2D(fin, fout, is_first=is_first, omega0=om, sigma0=sc).to(DEV)
+    rng = np.random.default_rng(9)
+    if is_first:
+        x_np = rng.uniform(-1, 1, (n, fin)).astype(np.float32)
+    else:
+        x_np = (0.3 * (rng.standard_normal((n, fin)) + 1j * rng.standard_normal((n, fin)))).astype(np.complex64)
+    g_np = (rng.standard_normal((n, fout)) + 1j * rng.standard_normal((n, fout))).astype(np.complex64)
+    x = torch.tensor(x_np, device=DEV, requires_grad=not is_first)
+    out = layer(x)
+    out.backward(torch.tensor(g_np, device=DEV))
+    torch.cuda.synchronize()
+    got = {"W": layer.linear.weight.grad, "b": layer.linear.bias.grad, "V": layer.scale_orth.weight.grad,
+           "c": layer.scale_orth.bias.grad}
+    if not is_first:
+        got["x"] = x.grad
+    got = {k: v.cpu().numpy() for k, v in got.items()}
+    got["out"] = out.detach().cpu().numpy()
+
+    def ref(double):
+        cd = torch.complex128 if double else torch.complex64
+        rd = torch.float64 if double else torch.float32
+        pd = rd if is_first else cd
+        W = layer.linear.weight.detach().cpu().to(pd).requires_grad_(True)
+        b = layer.linear.bias.detach().cpu().to(pd).requires_grad_(True)
+        V = layer.scale_orth.weight.detach().cpu().to(pd).requires_grad_(True)
+        c = layer.scale_orth.bias.detach().cpu().to(pd).requires_grad_(True)
+        xx = torch.tensor(x_np).to(pd).requires_grad_(not is_first)
+        o = torch_ref.gabor2d(F.linear(xx, W, b), F.linear(xx, V, c), om, sc)
+        # real loss whose gradient w.r.t. o is g (PyTorch convention: grad = dL/dRe + j dL/dIm)
+        gg = torch.tensor(g_np).to(cd)
+        (o.real * gg.real + o.imag * gg.imag).sum().backward()
+        r = {"W": W.grad, "b": b.grad, "V": V.grad, "c": c.grad, "out": o.detach()}
+        if not is_first:
+            r["x"] = xx.grad
+        return {k: v.numpy() for k, v in r.items()}
+
+    r64, r32 = ref(True), ref(False)
+    for k in got:
+        ref_err = relmax(r32[k], r64[k])
+        assert relmax(got[k], r64[k]) <= 4 * ref_err + 3e-6, k

@@ -241,3 +241,117 @@ extern "C" int wire_real_layer_bwd(void* stream, int kind, const float* g_act, c
                            g_b, nullptr, nullptr));
   return WIRE_OK;
 }
+
+// ---------------------------------------------------------------------------
+// ComplexGaborLayer2D (modules/wire2d.py:21-67) on native tensors: both Linears of the layer are ONE GEMM
+// ([n, Pin] x [Pin -> 2 Pout], 128-column groups (lin_re | lin_im | sy_re | sy_im)).
+// ---------------------------------------------------------------------------
+namespace {
+struct Layer2dWs {
+  int Pin, Pout, S, ldu;
+  int64_t xb, linsy, out, gact, glinsy, gxb, gup, btf, btd, bias, slab, bslab, crp, total;
+};
+Layer2dWs layer2d_ws(int64_t n, int in, int out) {
+  Layer2dWs w{};
+  w.Pin = rup(2 * in, 64);
+  w.Pout = rup(2 * out, 64);
+  w.ldu = w.Pout / 2;
+  w.S = gemm_tn_splits(n, 2 * w.Pout, w.Pin, 64);
+  int64_t off = 0;
+  auto take = [&](int64_t cnt) { int64_t o = off; off += rup64(cnt, 64); return o; };
+  w.xb = take(n * w.Pin);
+  w.linsy = take(n * 2 * w.Pout);
+  w.out = take(n * w.Pout);
+  w.gact = take(n * w.Pout);
+  w.glinsy = take(n * 2 * w.Pout);
+  w.gxb = take(n * w.Pin);
+  w.gup = take(n * 2 * w.ldu);
+  w.btf = take((int64_t)2 * w.Pout * w.Pin);
+  w.btd = take((int64_t)2 * w.Pout * w.Pin);
+  w.bias = take(2 * w.Pout);
+  w.slab = take((int64_t)w.S * 2 * w.Pout * w.Pin);
+  w.bslab = take((int64_t)w.S * 2 * w.Pout);
+  w.crp = take((int64_t)(colreduce_blocks(n) + 32) * w.ldu * 5);
+  w.total = off;
+  return w;
+}
+
+// forward into the workspace (linsy, out blocked); shared by fwd and bwd
+int layer2d_forward_ws(hipStream_t s, const Layer2dWs& w, float* W_, const void* x, const void* Wt, const void* b,
+                       const void* Vt, const void* c, float omega0, float scale0, int64_t n, int in, int out,
+                       int is_first) {
+  if (is_first) {
+    if (in > 4) return wire_fail_(WIRE_ERR_ARG, "is_first layers support in_features <= 4");
+    LCHK(launch_first_fwd(s, NK_WIRE2D, (const float*)x, n, in, (const float*)Wt, (const float*)b,
+                          (const float*)Vt, (const float*)c, out, w.Pout, omega0, scale0, nullptr, W_ + w.out));
+    return WIRE_OK;
+  }
+  LCHK(launch_c64_to_blocked(s, (const float*)x, n, in, w.Pin, W_ + w.xb));
+  LCHK(launch_pack_hidden(s, NK_WIRE2D, (const float*)Wt, (const float*)b, (const float*)Vt, (const float*)c, out,
+                          in, w.Pout, w.Pin, W_ + w.btf, W_ + w.btd, W_ + w.bias));
+  GemmEpiParams ep;
+  ep.bias = W_ + w.bias; ep.o0 = W_ + w.linsy; ep.o1 = W_ + w.out; ep.ld0 = 2 * w.Pout; ep.ld1 = w.Pout;
+  ep.omega = omega0; ep.scale = scale0; ep.kvalid = out;
+  LCHK(launch_gemm_nt(s, EPI_GABOR2D_FWD, W_ + w.xb, w.Pin, W_ + w.btf, w.Pin, n, 2 * w.Pout, w.Pin, ep));
+  return WIRE_OK;
+}
+}  // namespace
+
+extern "C" int64_t wire_layer2d_ws_bytes(int64_t n, int in_features, int out_features) {
+  if (n < 0 || in_features < 1 || out_features < 1) return wire_fail_(WIRE_ERR_ARG, "bad layer shape");
+  return layer2d_ws(n, in_features, out_features).total * 4 + 256;
+}
+
+extern "C" int wire_gabor2d_fwd(void* stream, const void* x, const void* W, const void* b, const void* V,
+                                const void* c, float omega0, float scale0, int64_t n, int in_features,
+                                int out_features, int is_first, void* act_out, void* ws, int64_t ws_bytes) {
+  if (n < 0 || in_features < 1 || out_features < 1 || !x || !W || !b || !V || !c || !act_out || !ws)
+    return wire_fail_(WIRE_ERR_ARG, "bad argument to wire_gabor2d_fwd");
+  if (n == 0) return WIRE_OK;
+  const Layer2dWs w = layer2d_ws(n, in_features, out_features);
+  if (ws_bytes < w.total * 4) return wire_fail_(WIRE_ERR_SIZE, "layer workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* W_ = (float*)ws;
+  if (int rc = layer2d_forward_ws(s, w, W_, x, W, b, V, c, omega0, scale0, n, in_features, out_features, is_first))
+    return rc;
+  LCHK(launch_blocked_to_c64(s, W_ + w.out, n, out_features, w.Pout, (float*)act_out));
+  return WIRE_OK;
+}
+
+extern "C" int wire_gabor2d_bwd(void* stream, const void* g_act, const void* x, const void* W, const void* b,
+                                const void* V, const void* c, float omega0, float scale0, int64_t n,
+                                int in_features, int out_features, int is_first, void* g_x, void* g_W, void* g_b,
+                                void* g_V, void* g_c, void* ws, int64_t ws_bytes) {
+  if (n <= 0 || in_features < 1 || out_features < 1 || !g_act || !x || !W || !b || !V || !c || !g_W || !g_b ||
+      !g_V || !g_c || !ws)
+    return wire_fail_(WIRE_ERR_ARG, "bad argument to wire_gabor2d_bwd");
+  const Layer2dWs w = layer2d_ws(n, in_features, out_features);
+  if (ws_bytes < w.total * 4) return wire_fail_(WIRE_ERR_SIZE, "layer workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* W_ = (float*)ws;
+  if (int rc = layer2d_forward_ws(s, w, W_, x, W, b, V, c, omega0, scale0, n, in_features, out_features, is_first))
+    return rc;
+  LCHK(launch_c64_to_blocked(s, (const float*)g_act, n, out_features, w.Pout, W_ + w.gact));
+  if (is_first) {
+    LCHK(launch_gabor2d_bwd_first_point(s, W_ + w.gact, W_ + w.out, (const float*)x, in_features,
+                                        (const float*)W, (const float*)b, (const float*)V, (const float*)c, n,
+                                        out_features, w.Pout, omega0, scale0, W_ + w.gup, w.ldu));
+    LCHK(launch_colreduce(s, W_ + w.gup, 2 * w.ldu, out_features, (const float*)x, in_features, n, W_ + w.crp,
+                          (float*)g_W, (float*)g_b));
+    LCHK(launch_colreduce(s, W_ + w.gup + w.ldu, 2 * w.ldu, out_features, (const float*)x, in_features, n,
+                          W_ + w.crp, (float*)g_V, (float*)g_c));
+    return WIRE_OK;
+  }
+  LCHK(launch_gabor2d_bwd_point(s, W_ + w.gact, W_ + w.linsy, W_ + w.out, n, w.Pout, omega0, scale0,
+                                W_ + w.glinsy));
+  if (g_x) {
+    GemmEpiParams ep; ep.o0 = W_ + w.gxb; ep.ld0 = w.Pin;
+    LCHK(launch_gemm_nt(s, EPI_STORE, W_ + w.glinsy, 2 * w.Pout, W_ + w.btd, 2 * w.Pout, n, w.Pin, 2 * w.Pout, ep));
+    LCHK(launch_blocked_to_c64(s, W_ + w.gxb, n, in_features, w.Pin, (float*)g_x));
+  }
+  LCHK(launch_gemm_tn(s, W_ + w.glinsy, 2 * w.Pout, W_ + w.xb, w.Pin, n, 2 * w.Pout, w.Pin, w.S, W_ + w.slab,
+                      W_ + w.bslab));
+  LCHK(launch_wgrad_reduce(s, NK_WIRE2D, W_ + w.slab, W_ + w.bslab, w.S, out_features, in_features, 2 * w.Pout,
+                           w.Pin, (float*)g_W, (float*)g_b, (float*)g_V, (float*)g_c));
+  return WIRE_OK;
+}

@@ -71,6 +71,14 @@ hipError_t launch_gabor_bwd_first_point(hipStream_t s, const float* g, const flo
                                         int64_t n, int K, int P, float omega, float scale, float* g_u,
                                         int ldu);
 
+// 2-D Gabor (wire2d) forms: linsy / g_linsy [n][2P] in (u | v | p | q) groups; first layer g_up [n][2 ldu]
+hipError_t launch_gabor2d_bwd_point(hipStream_t s, const float* g, const float* linsy, const float* out,
+                                    int64_t n, int P, float omega, float scale, float* g_linsy);
+hipError_t launch_gabor2d_bwd_first_point(hipStream_t s, const float* g, const float* out, const float* coords,
+                                          int D, const float* W0, const float* b0, const float* V0,
+                                          const float* c0, int64_t n, int K, int P, float omega, float scale,
+                                          float* g_up, int ldu);
+
 hipError_t launch_real_act_bwd_point(hipStream_t s, int kind, const float* g, const float* lin,
                                      const float* out, int64_t n, int P, float omega, float scale,
                                      float* g_lin);

@@ -876,6 +876,73 @@ __global__ void gabor_bwd_first_point_kernel(const float* __restrict__ g, const 
     g_u[row * ldu + f] = gu;
   }
 }
+// 2-D Gabor (modules/wire2d.py:56-67) activation gradient for the per-layer API.
+// g, out: [n][P] blocked planar; linsy, g_linsy: [n][2P] in 128-column groups (u | v | p | q) of 32 features.
+//   c = conj(out) g, t = -2 s0^2 Re c:  g_lin = t lin - j w0 c,  g_sy = t sy
+__global__ void gabor2d_bwd_point_kernel(const float* __restrict__ g, const float* __restrict__ linsy,
+                                         const float* __restrict__ out, long long n, int P, float omega,
+                                         float scale, float* __restrict__ g_linsy) {
+  const long long row = blockIdx.x;
+  const float m2s2 = -2.f * scale * scale;
+  for (int f = threadIdx.x; f < (P >> 1); f += blockDim.x) {
+    const size_t oc = (size_t)row * P + blk_col(f, 0);
+    const size_t lc = (size_t)row * 2 * P + ((f >> 5) << 7) + (f & 31);
+    const float gr = g[oc], gi = g[oc + 32], pr = out[oc], pi = out[oc + 32];
+    const float c_r = __builtin_fmaf(pr, gr, pi * gi);
+    const float c_i = __builtin_fmaf(pr, gi, -(pi * gr));
+    const float t = m2s2 * c_r;
+    g_linsy[lc] = __builtin_fmaf(t, linsy[lc], omega * c_i);
+    g_linsy[lc + 32] = __builtin_fmaf(t, linsy[lc + 32], -(omega * c_r));
+    g_linsy[lc + 64] = t * linsy[lc + 64];
+    g_linsy[lc + 96] = t * linsy[lc + 96];
+  }
+}
+// real first layer of wire2d: u = W0 x + b0, p = V0 x + c0;  g_u = t u + w0 Im c,  g_p = t p;  g_up [n][2 ldu]
+__global__ void gabor2d_bwd_first_point_kernel(const float* __restrict__ g, const float* __restrict__ out,
+                                               const float* __restrict__ coords, int D,
+                                               const float* __restrict__ W0, const float* __restrict__ b0,
+                                               const float* __restrict__ V0, const float* __restrict__ c0,
+                                               long long n, int K, int P, float omega, float scale,
+                                               float* __restrict__ g_up, int ldu) {
+  const long long row = blockIdx.x;
+  const float m2s2 = -2.f * scale * scale;
+  for (int f = threadIdx.x; f < ldu; f += blockDim.x) {
+    float gu = 0.f, gp = 0.f;
+    if (f < K) {
+      float u = b0[f], pp = c0[f];
+      for (int d = 0; d < D; ++d) {
+        const float x = coords[row * D + d];
+        u = __builtin_fmaf(x, W0[f * D + d], u);
+        pp = __builtin_fmaf(x, V0[f * D + d], pp);
+      }
+      const size_t c = (size_t)row * P + blk_col(f, 0);
+      const float gr = g[c], gi = g[c + 32], pr = out[c], pi = out[c + 32];
+      const float c_r = __builtin_fmaf(pr, gr, pi * gi);
+      const float c_i = __builtin_fmaf(pr, gi, -(pi * gr));
+      const float t = m2s2 * c_r;
+      gu = __builtin_fmaf(t, u, omega * c_i);
+      gp = t * pp;
+    }
+    g_up[row * 2 * ldu + f] = gu;
+    g_up[row * 2 * ldu + ldu + f] = gp;
+  }
+}
+hipError_t launch_gabor2d_bwd_point(hipStream_t s, const float* g, const float* linsy, const float* out,
+                                    int64_t n, int P, float omega, float scale, float* g_linsy) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gabor2d_bwd_point_kernel, dim3((unsigned)n), dim3(256), 0, s, g, linsy, out, (long long)n, P,
+                     omega, scale, g_linsy);
+  return hipGetLastError();
+}
+hipError_t launch_gabor2d_bwd_first_point(hipStream_t s, const float* g, const float* out, const float* coords,
+                                          int D, const float* W0, const float* b0, const float* V0,
+                                          const float* c0, int64_t n, int K, int P, float omega, float scale,
+                                          float* g_up, int ldu) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gabor2d_bwd_first_point_kernel, dim3((unsigned)n), dim3(256), 0, s, g, out, coords, D, W0,
+                     b0, V0, c0, (long long)n, K, P, omega, scale, g_up, ldu);
+  return hipGetLastError();
+}
 template <int ACT>
 __global__ void real_act_bwd_point_kernel(const float* __restrict__ g, const float* __restrict__ lin,
                                           const float* __restrict__ out, long long n, int P, float omega,

@@ -136,6 +136,52 @@ def gabor_layer(x, W, b, omega0: float, scale0: float, is_first: bool):
     return _GaborLayerFunction.apply(x, W, b, float(omega0), float(scale0), bool(is_first))
 
 
+class _Gabor2DLayerFunction(torch.autograd.Function):
+    """ComplexGaborLayer2D.forward (modules/wire2d.py:56-67): wire_gabor2d_fwd / wire_gabor2d_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, V, c, omega0: float, scale0: float, is_first: bool):
+        L = _lib.lib()
+        _require_cuda(x, "layer input")
+        _require_cuda(W, "layer weight")
+        dev = x.device
+        out_f, in_f = W.shape
+        xin = x.detach().to(torch.float32 if is_first else torch.complex64).contiguous()
+        n = xin.numel() // in_f
+        Wn, bn, Vn, cn = _native(W), _native(b), _native(V), _native(c)
+        ws_bytes = _lib.check(L.wire_layer2d_ws_bytes(n, in_f, out_f), "wire_layer2d_ws_bytes")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        act = torch.empty(tuple(x.shape[:-1]) + (out_f,), dtype=torch.complex64, device=dev)
+        _lib.check(L.wire_gabor2d_fwd(_stream_ptr(dev), xin.data_ptr(), Wn.data_ptr(), bn.data_ptr(),
+                                      Vn.data_ptr(), cn.data_ptr(), omega0, scale0, n, in_f, out_f,
+                                      int(is_first), act.data_ptr(), ws.data_ptr(), ws_bytes), "wire_gabor2d_fwd")
+        ctx.save_for_backward(xin, Wn, bn, Vn, cn)
+        ctx.cfg = (omega0, scale0, is_first, n, in_f, out_f, tuple(x.shape))
+        return act
+
+    @staticmethod
+    def backward(ctx, g_act):
+        L = _lib.lib()
+        xin, Wn, bn, Vn, cn = ctx.saved_tensors
+        omega0, scale0, is_first, n, in_f, out_f, xshape = ctx.cfg
+        dev = g_act.device
+        g = g_act.detach().to(torch.complex64).contiguous()
+        ws_bytes = _lib.check(L.wire_layer2d_ws_bytes(n, in_f, out_f), "wire_layer2d_ws_bytes")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        gW, gb, gV, gc = (torch.empty_like(t) for t in (Wn, bn, Vn, cn))
+        gx = None if is_first else torch.empty(xshape, dtype=torch.complex64, device=dev)
+        _lib.check(L.wire_gabor2d_bwd(_stream_ptr(dev), g.data_ptr(), xin.data_ptr(), Wn.data_ptr(),
+                                      bn.data_ptr(), Vn.data_ptr(), cn.data_ptr(), omega0, scale0, n, in_f,
+                                      out_f, int(is_first), None if gx is None else gx.data_ptr(),
+                                      gW.data_ptr(), gb.data_ptr(), gV.data_ptr(), gc.data_ptr(),
+                                      ws.data_ptr(), ws_bytes), "wire_gabor2d_bwd")
+        return gx, gW, gb, gV, gc, None, None, None
+
+
+def gabor2d_layer(x, W, b, V, c, omega0: float, scale0: float, is_first: bool):
+    return _Gabor2DLayerFunction.apply(x, W, b, V, c, float(omega0), float(scale0), bool(is_first))
+
+
 class _FinalLinearFunction(torch.autograd.Function):
     """Re(z W_f^T + b_f): wire_final_fwd / wire_final_bwd."""
 

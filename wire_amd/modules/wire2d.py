@@ -14,6 +14,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+from .. import functional as Fh
 from ._base import ActivationLayer, FinalLinear, HipINR, _param_value, _scalar_param
 
 
@@ -44,9 +45,9 @@ class ComplexGaborLayer2D(ActivationLayer):
                 self.scale_orth.weight, self._bias_or_zeros(self.scale_orth)]
 
     def forward(self, input):
-        raise NotImplementedError(
-            "stand-alone ComplexGaborLayer2D.forward is not exposed by libwire_hip ABI v1; "
-            "call the INR (fused path)")
+        return Fh.gabor2d_layer(input, self.linear.weight, self._bias_or_zeros(self.linear),
+                                self.scale_orth.weight, self._bias_or_zeros(self.scale_orth),
+                                self._w, self._s, self.is_first)
 
 
 class INR(HipINR):
