@@ -2,7 +2,11 @@
 """bench.py -- coord-samples/sec, forward+backward(+Adam), 4x256 complex WIRE MLP.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 and no WORLD_SIZE in the environment: this process starts N fresh rank processes itself
+(``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...``) BEFORE it
+touches the GPU, relays rank 0's JSON line and exits with the job's code.  Under a launcher (WORLD_SIZE set)
+it is one rank; it exits non-zero if the process group does not have exactly N ranks.
 
 Workload (BASELINE.json configs[1]): image fit with a
 4-hidden-layer WIRE of 256 COMPLEX features per layer (``hidden_features=363``
@@ -10,9 +14,11 @@ through the reference's API, modules/wire.py:119), D=2, O=3, omega0=20,
 sigma0=30; one step = one full pass of the hot path over a batch of 262 144
 coordinates per GPU (a 512 x 512 image per GPU; the N-GPU job fits a
 512 x 512N image, coordinate batch sharded contiguously, one RCCL all-reduce of
-the 2.1 MB flat gradient per step -> weak scaling): device-side randperm ->
+the 2.1 MB flat gradient per step -> weak scaling): per-rank shard of the epoch's
+shuffle (position-keyed bijection, wire_perm_indices -- cost independent of N) ->
 on-device coordinates -> forward -> MSE -> backward -> all-reduce -> Adam.
-Synthetic data (U[0,1) target), reference init under torch.manual_seed(0).
+Synthetic data (U[0,1) target), reference init under torch.manual_seed(0), rank 0's
+parameters broadcast to every replica.
 
 The JSON line also carries
   roofline     : dominant kernel class (the layer GEMMs) timed live with HIP
@@ -22,14 +28,21 @@ The JSON line also carries
                  is 6 bf16 MFMA products, so the ceiling of the algorithm is
                  the dense bf16 MFMA peak / 6 = 416.7 fp32-equivalent TFLOP/s;
                  with WIRE_SPLIT_BF16=0 (fp32-MFMA kernels) it is 157.3.
+                 mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs ... per SIMD) of that
+                 kernel from the committed PMC summary (profiles/pmc_traffic.json).
   cpu_baseline : the oracle's eager-PyTorch restatement of the reference's CPU
                  path (kind "port"), timed on this host's cores on a bounded
-                 sample of the same workload.
+                 sample of the same workload (BASELINE.md section 4).
+  extras       : the exact-fp32 family on the same workload, the reference-API width, forward-only
+                 inference, and BASELINE.json configs[3] / [4] (wire2d 1024^2; siren / gauss / relu /
+                 relu+posenc at 4x256) with bounded step counts.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,15 +50,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 256 flop/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (16x the fp32 MFMA rate)
 HIDDEN_FEATURES = 363           # -> K = int(363/sqrt(2)) = 256 complex features
 L, D, O = 4, 2, 3
 OMEGA0, SIGMA0 = 20.0, 30.0
 SIDE = 512                      # 512 x 512 = 262 144 coordinates per GPU
+
+
+# ---------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves (no GPU call before this point)
+# ---------------------------------------------------------------------------
+def spawn_ranks(n: int) -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def host_cores() -> int:
@@ -60,9 +85,21 @@ def host_cores() -> int:
     return max(1, n)
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(n_sample: int, iters: int):
-    """Reference CPU path (eager PyTorch restatement from oracle/) on a bounded
-    sample: fwd + bwd + Adam over n_sample coordinates of the same workload."""
+    """Reference CPU path (eager PyTorch restatement from oracle/) on a bounded sample:
+    1 warm-up + `iters` timed fwd + bwd + Adam steps over the first n_sample coordinates of the same workload,
+    and the same number of forward-only passes."""
+    import torch
     from oracle import torch_ref, wire_oracle as wo
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -74,49 +111,120 @@ def cpu_baseline(n_sample: int, iters: int):
     t0 = time.perf_counter()
     torch_ref.train_steps(p, coords, target, L, OMEGA0, OMEGA0, SIGMA0, 5e-3, iters)
     dt = time.perf_counter() - t0
+    with torch.no_grad():
+        torch_ref.wire_forward(p, coords, L, OMEGA0, OMEGA0, SIGMA0)
+        t1 = time.perf_counter()
+        for _ in range(iters):
+            torch_ref.wire_forward(p, coords, L, OMEGA0, OMEGA0, SIGMA0)
+        dtf = time.perf_counter() - t1
     return {"value": n_sample * iters / dt, "unit": "coord-samples/s", "cores": cores, "kind": "port",
-            "sample": f"{iters} fwd+bwd+Adam steps over the first {n_sample} coords of the 512x512 grid, "
-                      f"4x256 complex WIRE, torch {torch.__version__} CPU eager (oracle/torch_ref.py)"}
+            "cpu_model": cpu_model(), "forward_only_value": n_sample * iters / dtf,
+            "sample": f"{iters} timed fwd+bwd+Adam steps (after 1 warm-up) and {iters} forward-only passes over the "
+                      f"first {n_sample} coords of the 512x512 grid, 4x256 complex WIRE, torch {torch.__version__} "
+                      f"CPU eager, {cores} threads (oracle/torch_ref.py)"}
+
+
+def alg_flops(kind, K, Ln, Din, On):
+    """SURVEY 8(d) algorithmic flop per sample, fwd + bwd."""
+    if kind == "wire":
+        return 24 * K * K * Ln + 4 * Din * K + 12 * K * On
+    if kind == "wire2d":
+        return 48 * K * K * Ln + 8 * Din * K + 12 * K * On
+    return 6 * K * K * Ln + 4 * Din * K + 6 * K * On
+
+
+def read_prof(lib):
+    ms = (C.c_double * 4)()
+    cnt = (C.c_int64 * 4)()
+    fl = (C.c_double * 4)()
+    lib.wire_prof_read(ms, cnt, fl)
+    return list(ms), list(cnt), list(fl)
+
+
+def timed_config(dev, lib, kind, side, hf, steps, warmup=2, **kw):
+    """fwd + MSE + bwd + Adam throughput of one net kind over a side x side grid (whole grid per step, hashed
+    shuffle), with the per-launch time and algorithmic rate of its dominant GEMM class."""
+    import torch
+    from wire_amd.modules import models
+    from wire_amd.trainer import FusedTrainer
+    torch.manual_seed(0)
+    model = models.get_INR(nonlin=kind, in_features=D, out_features=O, hidden_features=hf, hidden_layers=L, **kw).to(dev)
+    K = model._arch["width"]
+    n = side * side
+    g = torch.Generator().manual_seed(0)
+    tr = FusedTrainer(model, (side, side), torch.rand(n, O, generator=g), lr=5e-3, niters=2000)
+    for e in range(warmup):
+        tr.step_hashed(e)
+    lib.wire_prof_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for e in range(steps):
+        tr.step_hashed(warmup + e)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    lib.wire_prof_enable(0)
+    ms, cnt, fl = read_prof(lib)
+    Din = D if not kw.get("pos_encode") else model.positional_encoding.out_dim
+    F = alg_flops(kind, K, L, Din, O)
+    klass = max(range(3), key=lambda i: ms[i])
+    avg_ms = ms[klass] / max(1, cnt[klass])
+    gemm_tf = fl[klass] / max(1, cnt[klass]) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    split = lib.wire_tune_get(b"split_bf16") == 1
+    peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_FP32_MFMA_TFLOPS
+    res = {"samples_per_s": n / dt, "ms_per_step": dt * 1e3, "K": K, "coords_per_step": n, "steps": steps,
+           "alg_flop_per_sample": F, "whole_step_tflops": n / dt * F / 1e12,
+           "whole_step_frac": n / dt * F / 1e12 / peak,
+           "whole_step_frac_of_fp32_mfma_peak": n / dt * F / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+           "dominant_gemm": {"class": ["forward", "data gradient", "weight gradient"][klass],
+                             "avg_launch_ms": avg_ms, "alg_tflops": gemm_tf, "frac": gemm_tf / peak, "peak": peak}}
+    del tr, model
+    torch.cuda.empty_cache()
+    return res
 
 
 def extras(dev, lib):
-    """Secondary numbers (not the headline): the same net through the reference's API width
-    (hidden_features=256 -> K=181, padded to 192 on the matrix cores) and forward-only inference."""
+    """Secondary numbers (not the headline)."""
+    import torch
     from wire_amd.modules import models
     from wire_amd.trainer import FusedTrainer
     res = {}
-    g = torch.Generator().manual_seed(0)
-    target = torch.rand(SIDE * SIDE, O, generator=g)
-    for tag, hf in (("k181_api_hidden_features_256", 256), ("k256_literal", HIDDEN_FEATURES)):
-        torch.manual_seed(0)
-        model = models.get_INR(nonlin="wire", in_features=D, out_features=O, hidden_features=hf,
-                               hidden_layers=L, first_omega_0=OMEGA0, hidden_omega_0=OMEGA0, scale=SIGMA0).to(dev)
-        K = model._arch["width"]
-        tr = FusedTrainer(model, (SIDE, SIDE), target, lr=5e-3, niters=2000)
-        if hf == 256:
-            for _ in range(2):
-                tr.step(torch.randperm(SIDE * SIDE, device=dev))
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                tr.step(torch.randperm(SIDE * SIDE, device=dev))
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 10
-            F = 24 * K * K * L + 4 * D * K + 12 * K * O
-            res[tag] = {"train_samples_per_s": SIDE * SIDE / dt, "K": K,
-                        "frac_of_fp32_mfma_peak": SIDE * SIDE / dt * F / 1e12 / PEAK_FP32_MFMA_TFLOPS}
-        else:
-            tr.render()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(5):
-                tr.render()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 5
-            Ff = 8 * K * K * L + 2 * D * K + 4 * K * O
-            res["forward_only_" + tag] = {"samples_per_s": SIDE * SIDE / dt, "K": K,
-                                          "frac_of_fp32_mfma_peak": SIDE * SIDE / dt * Ff / 1e12 / PEAK_FP32_MFMA_TFLOPS}
-        del tr, model
+    wire_kw = dict(first_omega_0=OMEGA0, hidden_omega_0=OMEGA0, scale=SIGMA0)
+    # the reference-API width: hidden_features=256 -> K = 181 (padded to 192 on the matrix cores)
+    res["k181_api_hidden_features_256"] = timed_config(dev, lib, "wire", SIDE, 256, 10, **wire_kw)
+    # forward-only dense inference of the headline net
+    torch.manual_seed(0)
+    model = models.get_INR(nonlin="wire", in_features=D, out_features=O, hidden_features=HIDDEN_FEATURES,
+                           hidden_layers=L, **wire_kw).to(dev)
+    K = model._arch["width"]
+    tr = FusedTrainer(model, (SIDE, SIDE), torch.zeros(SIDE * SIDE, O), lr=5e-3)
+    tr.render()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        tr.render()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    Ff = 8 * K * K * L + 2 * D * K + 4 * K * O
+    res["forward_only_k256_literal"] = {"samples_per_s": SIDE * SIDE / dt, "K": K,
+                                        "frac_of_fp32_mfma_peak": SIDE * SIDE / dt * Ff / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+    del tr, model
+    torch.cuda.empty_cache()
+    # the exact-fp32 family (fp32 MFMA, 3-multiplication complex GEMMs) on the headline workload: the
+    # north-star's literal realisation and the fallback should the split ever be contested
+    if lib.wire_tune_get(b"split_bf16") == 1:
+        lib.wire_tune_set(b"split_bf16", 0)
+        try:
+            res["fp32_mfma_family"] = timed_config(dev, lib, "wire", SIDE, HIDDEN_FEATURES, 8, **wire_kw)
+            res["fp32_mfma_family"]["dtype"] = "f32 (v_mfma_f32_32x32x2_f32, 3-multiplication complex product)"
+        finally:
+            lib.wire_tune_set(b"split_bf16", 1)
+    # BASELINE.json configs[3] and [4] through the same trainer (bounded steps)
+    res["cfg4_wire2d_4x256_1024x1024"] = timed_config(dev, lib, "wire2d", 1024, 256, 4, first_omega_0=10.0,
+                                                      hidden_omega_0=10.0, scale=10.0)
+    res["cfg5_siren_4x256"] = timed_config(dev, lib, "siren", SIDE, 256, 8, first_omega_0=30.0, hidden_omega_0=30.0)
+    res["cfg5_gauss_4x256"] = timed_config(dev, lib, "gauss", SIDE, 256, 8, scale=10.0)
+    res["cfg5_relu_4x256"] = timed_config(dev, lib, "relu", SIDE, 256, 8)
+    res["cfg5_relu_posenc_4x256"] = timed_config(dev, lib, "relu", SIDE, 256, 8, pos_encode=True, sidelength=512)
     return res
 
 
@@ -129,17 +237,35 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--hidden-features", type=int, default=HIDDEN_FEATURES)
+    ap.add_argument("--shuffle", choices=["hashed", "randperm"], default="hashed",
+                    help="hashed: per-rank slice of a position-keyed bijection (default); randperm: torch.randperm "
+                         "of the whole grid on every rank, the reference's literal call")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))          # nothing above has touched the GPU
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"error: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
+    backend = os.environ.get("WIRE_BENCH_BACKEND", "nccl")
     # one process per GPU.  (Rehearsal on a 1-GPU box: WIRE_BENCH_BACKEND=gloo lets several ranks
     # share cuda:0 -- RCCL itself refuses two ranks on one device.)
     ndev = max(1, torch.cuda.device_count())
+    if world > ndev and backend == "nccl":
+        if rank == 0:
+            print(f"error: {world} ranks need {world} GPUs, {ndev} visible (WIRE_BENCH_BACKEND=gloo rehearses "
+                  f"several ranks on one card)", file=sys.stderr)
+        sys.exit(3)
     dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
-    backend = os.environ.get("WIRE_BENCH_BACKEND", "nccl")
     if world > 1 or os.environ.get("WIRE_DP_FORCE", "0") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -147,8 +273,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        if dist.get_world_size() != args.gpus:
+            print(f"error: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}", file=sys.stderr)
+            sys.exit(2)
 
     from wire_amd import _lib
     from wire_amd.modules import models
@@ -165,10 +292,14 @@ def main():
     g = torch.Generator().manual_seed(0)
     target = torch.rand(npts, O, generator=g)
     tr = FusedTrainer(model, (H, W), target, lr=5e-3, niters=2000, micro_shards=args.micro_shards)
+    epoch = [0]
 
     def one_step():
-        idx = tr.permutation()                          # torch.randperm per epoch (wire_image_denoise.py:142),
-        loss = tr.step(idx)                             # generated on a side stream under the previous step
+        if args.shuffle == "hashed":
+            loss = tr.step_hashed(epoch[0])             # this rank's slice of the epoch's shuffle, on the device
+        else:
+            loss = tr.step(tr.permutation())            # torch.randperm(H*W) per epoch (wire_image_denoise.py:142)
+        epoch[0] += 1
         tr.scheduler_step()
         return loss
 
@@ -188,10 +319,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     lib.wire_prof_enable(0)
-    ms = (C.c_double * 4)()
-    cnt = (C.c_int64 * 4)()
-    fl = (C.c_double * 4)()
-    lib.wire_prof_read(ms, cnt, fl)
+    ms, cnt, fl = read_prof(lib)
     if world > 1:
         tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -200,7 +328,7 @@ def main():
 
     if rank == 0:
         n_gpu_batch = npts // world
-        F = 24 * K * K * L + 4 * D * K + 12 * K * O      # SURVEY 8(d) algorithmic flop / sample
+        F = alg_flops("wire", K, L, D, O)               # SURVEY 8(d) algorithmic flop / sample
         value = npts * args.steps / dt
         split = lib.wire_tune_get(b"split_bf16") == 1
         if split:
@@ -217,12 +345,14 @@ def main():
         achieved = alg_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic = None
         hbm = None
+        mfma_busy = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 fam = tj.get("split_bf16", {}) if split else tj.get("fp32_mfma", tj)
                 traffic = fam.get(str(klass))
+                mfma_busy = (tj.get("mfma_busy", {}).get("split_bf16" if split else "fp32_mfma", {}) or {}).get(str(klass))
                 # HBM rate of the GEMMs from the PMC byte counts per launch (committed profile) and the launch
                 # times measured in THIS run: evidence of fusion quality, not the bound
                 if all(str(i) in fam and cnt[i] > 0 for i in range(3)) and args.micro_shards == 1 and world == 1:
@@ -243,9 +373,11 @@ def main():
             "config": {"workload": f"512x{512 * world} image fit, WIRE 4 hidden x {K} complex "
                                    f"(hidden_features={args.hidden_features}), D=2 O=3 omega0=20 sigma0=30, "
                                    f"batch=262144 coords/GPU, fwd+MSE+bwd+Adam per step",
-                       "global_batch": npts, "parallelism": f"dp{world}", "micro_shards": args.micro_shards},
+                       "global_batch": npts, "parallelism": f"dp{world}", "micro_shards": args.micro_shards,
+                       "shuffle": args.shuffle, "backend": backend if world > 1 else None},
             "roofline": {"bound": "mfma", "kernel": names[klass], "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "mfma_busy": mfma_busy,
                          "avg_launch_ms": avg_ms, "launches": int(cnt[klass]),
                          "alg_flops_per_launch": alg_per_launch,
                          "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per fp32 product; "
@@ -262,9 +394,10 @@ def main():
         if world == 1 and not args.no_extras:
             out["extras"] = extras(dev, lib)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(32768, 2)
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(65536, 3)
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

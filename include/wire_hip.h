@@ -129,8 +129,9 @@ int wire_train_fwd_bwd(void* stream, const wire_net_desc* d, const float* packed
 
 /* ---- per-layer path (ComplexGaborLayer.forward, modules/wire.py:88-93) -- */
 /* x: [n][in] f32 when is_first else [n][in] c64; W: [out][in] f32/c64;
- * act_out [n][out] c64 (interleaved); lin_out (optional, may be NULL) has the
- * dtype of W's product: f32 [n][out] if is_first else c64.
+ * act_out [n][out] c64 (interleaved); lin_out (optional, may be NULL) receives the pre-activation
+ * `lin` of modules/wire.py:89 in the dtype of W's product: f32 [n][out] if is_first else c64.
+ * The GEMM runs on the family the tuning knobs select -- the same kernels as wire_mlp_fwd.
  * ws: scratch of wire_layer_ws_bytes(n, in, out).                          */
 int64_t wire_layer_ws_bytes(int64_t n, int in_features, int out_features);
 int wire_gabor_fwd(void* stream, const void* x, const void* W, const void* b,
@@ -173,6 +174,13 @@ int wire_real_layer_bwd(void* stream, int kind, const float* g_act, const float*
 int wire_coords_from_index(void* stream, const int64_t* idx, int64_t first,
                            int64_t n, const float* tx, int W, const float* ty,
                            int H, const float* tz, int T, float* coords);
+/* The per-epoch shuffle (torch.randperm(H*W) at wire_image_denoise.py:142, wire_occupancy.py:137) as a keyed
+ * bijection pi_seed of [0, n_total) evaluated per position: idx_out[r] = pi_seed(first + r), r < count.  A rank
+ * of a data-parallel job generates only the slice of the epoch's permutation it trains on (cost O(count),
+ * independent of n_total and of the world size).  Integer arithmetic, bit-exact with oracle/wire_oracle.py:
+ * hash_perm; NOT the sequence torch.randperm draws.                                                  */
+int wire_perm_indices(void* stream, uint64_t seed, int64_t n_total, int64_t first, int64_t count,
+                      int64_t* idx_out);
 /* loss = mean((y - target[idx])^2) over n*O elements scaled by `weight`
  * (= n/B for a shard of a global batch B; 1 for a whole batch);
  * g_y = weight * 2/(n*O) * (y - t).  loss_out[0] += is NOT used: it is

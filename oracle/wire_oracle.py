@@ -483,3 +483,41 @@ def wire_flops_per_sample(K: int, L: int, D: int, O: int, backward: bool = True)
     if backward:
         return 24 * K * K * L + 4 * D * K + 12 * K * O
     return 8 * K * K * L + 2 * D * K + 4 * K * O
+
+
+# --------------------------------------------------------------------------
+# position-keyed shuffle (wire_amd: wire_perm_indices; replaces torch.randperm of
+# wire_image_denoise.py:142 / wire_occupancy.py:137 in the sharded loops)
+# --------------------------------------------------------------------------
+def _splitmix64(z: int) -> int:
+    M = (1 << 64) - 1
+    z = (z + 0x9E3779B97F4A7C15) & M
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    return z ^ (z >> 31)
+
+
+def hash_perm(n_total: int, seed: int, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+    """pi_seed(first .. first+count) of the keyed bijection of [0, n_total) that libwire_hip's
+    perm_indices_kernel evaluates (wire_point.hip): four rounds of x = (x*M_r + K_r) mod 2^b, x ^= x >> s on
+    the smallest power-of-two domain, cycle-walking back into [0, n_total).  Test infrastructure."""
+    count = n_total - first if count is None else count
+    b = 0
+    while b < 63 and (1 << b) < n_total:
+        b += 1
+    b = max(b, 1)
+    sh = max(b // 2, 1)
+    mask = np.uint64((1 << b) - 1)
+    m = [np.uint64(_splitmix64((seed * 8 + r) & ((1 << 64) - 1)) | 1) for r in range(4)]
+    k = [np.uint64(_splitmix64((seed * 8 + 4 + r) & ((1 << 64) - 1))) for r in range(4)]
+    x = np.arange(first, first + count, dtype=np.uint64)
+    todo = np.ones(count, dtype=bool)
+    with np.errstate(over="ignore"):
+        while todo.any():
+            v = x[todo]
+            for r in range(4):
+                v = (v * m[r] + k[r]) & mask
+                v ^= v >> np.uint64(sh)
+            x[todo] = v
+            todo[todo] = v >= np.uint64(n_total)
+    return x.astype(np.int64)

@@ -91,3 +91,78 @@ def relmax(a, b):
     d = np.abs(a - b).max()
     s = np.abs(b).max()
     return float(d / s) if s > 0 else float(d)
+
+
+# ---------------------------------------------------------------------------
+# parity bound of SURVEY.md section 7 (protocol step ii) and a log of what was measured
+# ---------------------------------------------------------------------------
+RATIO_LOG = []
+
+
+def within_ref(err_build, err_ref, label, factor=2.0, floor=1e-6):
+    """err_build <= factor * err_ref + floor, where err_ref is the reference arithmetic's own fp32-vs-fp64
+    error on the same inputs (``err_build <= 2 err_ref + 1e-6``).  Every comparison is
+    logged; conftest.py writes the log to gpurun_out/parity_ratios.txt at the end of a GPU session."""
+    RATIO_LOG.append((label, float(err_build), float(err_ref)))
+    assert err_build <= factor * err_ref + floor, \
+        f"{label}: err_build {err_build:.3e} > {factor} x err_ref {err_ref:.3e} + {floor:g}"
+
+
+def final_bias_within_ref(g, g64, err_y_ref, ymax, O, label, factor=2.0, floor=1e-6, resid_max=0.0):
+    """The gradient of the final bias is the MEAN of dL/dy: g_bf[o] = (2 / (n O)) sum_n (y - t)[n, o]
+    (modules/wire.py:156-157 + the MSE of wire_image_denoise.py:153).  It is O <= 3 numbers -- for O = 1 a single
+    one -- that can cancel to nearly zero, so max|error| / max|value| over the tensor itself is one noisy draw,
+    not a statistic.  The protocol's bound on the forward output propagates exactly instead:
+        |dg_bf[o]| <= (2 / (n O)) sum_n |dy[n, o]| <= (2 / O) max|dy| <= (2 / O) (2 err_ref_y + 1e-6) max|y64|.
+    The fp32 sum of the residuals y - t itself rounds relative to THEIR size, so the scale of the bound is
+    max(max|y64|, max|y64 - t|) when the caller passes the residuals' maximum (a net whose outputs are still
+    small next to the target: relu at init)."""
+    g, g64 = np.asarray(g, np.float64).ravel(), np.asarray(g64, np.float64).ravel()
+    err = np.abs(g - g64).max() / ((2.0 / O) * max(float(ymax), float(resid_max)))
+    RATIO_LOG.append((label + " [forward-propagated bound]", float(err), float(err_y_ref)))
+    assert err <= factor * err_y_ref + floor, \
+        f"{label}: |dg| / ((2/O) max|y|) = {err:.3e} > {factor} x err_ref_y {err_y_ref:.3e} + {floor:g}"
+
+
+def family_ctx(fam):
+    """Context manager selecting a GEMM family of libwire_hip ('x3' split-bf16 on the bf16 MFMA -- the default
+    and the one bench.py times --, '3m' / '4m' fp32 MFMA) and restoring the default afterwards."""
+    import contextlib
+    from wire_amd import _lib
+
+    @contextlib.contextmanager
+    def ctx():
+        L = _lib.lib()
+        sb, c3 = {"x3": (1, 1), "3m": (0, 1), "4m": (0, 0)}[fam]
+        _lib.check(L.wire_tune_set(b"split_bf16", sb))
+        _lib.check(L.wire_tune_set(b"complex_3m", c3))
+        try:
+            yield L
+        finally:
+            _lib.check(L.wire_tune_set(b"split_bf16", 1))
+            _lib.check(L.wire_tune_set(b"complex_3m", 1))
+    return ctx()
+
+
+def wire_oracle_grads_chunked(P, coords, target, L, om1, om, sc, double, chunk=16384):
+    """Loss and every parameter gradient of the MSE over ALL rows (mean over n x O elements,
+    wire_image_denoise.py:153), evaluated by the numpy oracle in row chunks so that BASELINE.json's full batch
+    (262 144 x 256 complex128 activations = 0.5 GB per layer) stays small.  Gradients are summed in the chunk's
+    own precision.  Returns (y, loss, grads)."""
+    from oracle import wire_oracle as wo
+    rdt = np.float64 if double else np.float32
+    p = wo.cast_params(P, double)
+    n, O = target.shape[0], target.shape[1]
+    ys, grads, sq = [], None, 0.0
+    for s in range(0, n, chunk):
+        c = coords[s:s + chunk].astype(rdt)
+        t = target[s:s + chunk].astype(rdt)
+        y, cache = wo.wire_forward(p, c, L, rdt(om1), rdt(om), rdt(sc), keep=True)
+        diff = y - t
+        sq += float(np.square(diff.astype(np.float64)).sum())
+        gy = (rdt(2.0) / rdt(n * O)) * diff
+        g = wo.wire_backward(p, cache, gy, L, rdt(om1), rdt(om), rdt(sc))
+        grads = g if grads is None else {k: grads[k] + g[k] for k in g}
+        ys.append(y)
+        del cache
+    return np.concatenate(ys, 0), sq / (n * O), grads

@@ -4,8 +4,9 @@ modules) against the oracle / the reference-generated golden vectors.
 Tolerances (SURVEY.md section 7 "Precision"): the reference's own fp32 path is
 only accurate to err_ref = |y_ref32 - y_ref64| against its fp64 twin, and that
 error grows with omega0 and depth.  Whole-network checks therefore require
-    err_build = |y_hip - y64| / max|y64|  <=  4 * err_ref + 3e-6
-and per-layer checks on identical inputs require 1e-5 relative to the layer max.
+    err_build = |y_hip - y64| / max|y64|  <=  2 * err_ref + 1e-6        (_util.within_ref)
+and per-layer checks on identical inputs require 1e-5 relative to the layer max (forward; 2e-5 backward).
+The measured err_build / err_ref of every comparison is written to gpurun_out/parity_ratios.txt.
 """
 import ctypes as C
 import os
@@ -15,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import FULL, ROOT, SMALL, build_model, load_golden, meta, oracle_run, params_np, relmax
+from _util import FULL, ROOT, SMALL, build_model, family_ctx, load_golden, meta, oracle_run, params_np, relmax, within_ref, final_bias_within_ref
 from oracle import wire_oracle as wo
 
 pytestmark = pytest.mark.gpu
@@ -40,6 +41,24 @@ def hip_forward_backward(model, rec):
     return y.detach().cpu().numpy(), float(loss.detach()), grads
 
 
+def _check_grads(grads, g64, g32, label, err_y_ref, y64, extra_ref=None, target=None):
+    """Every parameter gradient against the fp64 oracle with the fp32 oracle's own error as yardstick
+    (err_build <= 2 err_ref + 1e-6); the final bias through the forward-propagated bound
+    (_util.final_bias_within_ref)."""
+    last = max(int(k.split(".")[1]) for k in grads)
+    O = np.asarray(y64).shape[-1]
+    for k, g in grads.items():
+        if k == f"net.{last}.bias":
+            resid = 0.0 if target is None else np.abs(np.asarray(y64) - np.asarray(target).reshape(np.shape(y64))).max()
+            final_bias_within_ref(wo.as_real_pairs(g), wo.as_real_pairs(np.asarray(g64[k])), err_y_ref,
+                                  np.abs(y64).max(), O, f"{label} grad {k}", resid_max=resid)
+            continue
+        ref_err = relmax(g32[k], g64[k])
+        if extra_ref is not None:
+            ref_err = max(ref_err, extra_ref[k])
+        within_ref(relmax(g, g64[k]), ref_err, f"{label} grad {k}")
+
+
 def test_extension_loaded():
     from wire_amd import _lib
     assert _lib.lib().wire_abi_version() == 1
@@ -52,11 +71,10 @@ def test_small_forward_backward(name):
     model = load_small(rec, build_model(rec))
     y, loss, grads = hip_forward_backward(model, rec)
     err_ref = relmax(rec["y"], rec["y64"])
-    assert relmax(y, rec["y64"]) <= 4 * err_ref + 3e-6
+    within_ref(relmax(y, rec["y64"]), err_ref, f"{name} y")
     assert abs(loss - float(rec["loss64"])) <= 1e-5 * abs(float(rec["loss64"])) + 10 * err_ref
-    for k, g in grads.items():
-        gref_err = relmax(rec["g:" + k], rec["g64:" + k])
-        assert relmax(g, rec["g64:" + k]) <= 4 * gref_err + 3e-6, k
+    _check_grads(grads, {k: rec["g64:" + k] for k in grads}, {k: rec["g:" + k] for k in grads}, name, err_ref,
+                 rec["y64"], target=rec["target"])
 
 
 @pytest.mark.parametrize("name", FULL)
@@ -67,17 +85,17 @@ def test_full_configs(name):
     P = params_np(model)
     y, loss, grads = hip_forward_backward(model, rec)
     err_ref = relmax(rec["y"], rec["y64"])
-    assert relmax(y, rec["y64"]) <= 4 * err_ref + 3e-6
+    within_ref(relmax(y, rec["y64"]), err_ref, f"{name} y")
     # full gradients against the fp64 oracle on the same weights
     _, _, g64, _ = oracle_run(rec, P, double=True)
     _, _, g32, _ = oracle_run(rec, P, double=False)
+    _check_grads(grads, g64, g32, name, err_ref, rec["y64"], target=rec["target"])
     for k, g in grads.items():
-        # a gradient inherits the forward pass's round-off (err_ref) on top of its own
-        ref_err = relmax(g32[k], g64[k]) + 0.05 * err_ref
-        assert relmax(g, g64[k]) <= 4 * ref_err + 3e-6, k
+        # ... and directly against the heads of the REFERENCE's fp64 gradients held by the fixture
+        ref_err = max(relmax(g32[k], g64[k]), 0.5 * err_ref)
         head = g[:8, :8] if g.ndim == 2 else g[:16]
         scale = float(rec["g64norm:" + k])
-        assert np.abs(head - rec["g64head:" + k]).max() <= (4 * ref_err + 3e-6) * scale, k
+        assert np.abs(head - rec["g64head:" + k]).max() <= (2 * ref_err + 1e-6) * scale, k
 
 
 def _set_family(L, split_bf16, complex_3m):
@@ -105,7 +123,7 @@ def test_gemm_families_accuracy():
                 y, loss, grads = hip_forward_backward(model, rec)
                 err_ref = relmax(rec["y"], rec["y64"])
                 e = relmax(y, rec["y64"])
-                assert e <= 4 * err_ref + 3e-6, (fam, name)
+                within_ref(e, err_ref, f"family {fam} {name} y")
                 errs[(fam, name)] = (e, err_ref)
     finally:
         _set_family(L, 1, 1)
@@ -131,12 +149,10 @@ def test_fp32_mfma_family_full_configs(name):
         P = params_np(model)
         y, loss, grads = hip_forward_backward(model, rec)
         err_ref = relmax(rec["y"], rec["y64"])
-        assert relmax(y, rec["y64"]) <= 4 * err_ref + 3e-6
+        within_ref(relmax(y, rec["y64"]), err_ref, f"fp32-mfma {name} y")
         _, _, g64, _ = oracle_run(rec, P, double=True)
         _, _, g32, _ = oracle_run(rec, P, double=False)
-        for k, g in grads.items():
-            ref_err = relmax(g32[k], g64[k]) + 0.05 * err_ref
-            assert relmax(g, g64[k]) <= 4 * ref_err + 3e-6, k
+        _check_grads(grads, g64, g32, f"fp32-mfma {name}", err_ref, rec["y64"], target=rec["target"])
     finally:
         _set_family(L, 1, 1)
 
@@ -173,10 +189,9 @@ def test_ragged_row_counts_against_oracle(n):
     err_ref = max(relmax(y32, y64), relmax(yb32, yb64))
     # ... and so is the scale: one row's outputs can all be small, its round-off is not
     scale = max(np.abs(y64).max(), np.abs(yb64).max())
-    assert np.abs(y - y64).max() <= (4 * err_ref + 3e-6) * scale
-    for k, g in grads.items():
-        ref_err = max(relmax(g32[k], g64[k]), relmax(gb32[k], gb64[k])) + 0.05 * err_ref
-        assert relmax(g, g64[k]) <= 4 * ref_err + 3e-6, k
+    within_ref(np.abs(y - y64).max() / scale, err_ref, f"ragged n={n} y")
+    _check_grads(grads, g64, g32, f"ragged n={n}", err_ref, np.array([[scale] * 3]),
+                 extra_ref={k: relmax(gb32[k], gb64[k]) for k in grads})
 
 
 @pytest.mark.parametrize("name", ["small_wire_d2", "small_wire_d3", "small_wire_hi"])
@@ -305,7 +320,7 @@ def test_full_size_sampled_vs_oracle(big):
     y64 = wo.wire_forward(wo.cast_params(P, True), c.astype(np.float64), 4, 20.0, 20.0, 30.0)
     y32 = wo.wire_forward(wo.cast_params(P, False), c, 4, np.float32(20.0), np.float32(20.0), np.float32(30.0))
     err_ref = relmax(y32, y64)
-    assert relmax(y[idx].cpu().numpy(), y64) <= 4 * err_ref + 3e-6
+    within_ref(relmax(y[idx].cpu().numpy(), y64), err_ref, "full-size sampled y")
 
 
 def test_full_size_gradient_linearity_and_additivity(big):
@@ -482,6 +497,24 @@ def test_occupancy_style_minibatches_match_oracle():
     P64 = wo.cast_params(params_np(model), True)
     P32 = wo.cast_params(params_np(model), False)
     perm = torch.randperm(npts)
+    # yardstick: the reference arithmetic's own fp32 round-off.  A 280-400-row minibatch is a small sample of it (one
+    # max over few rows; at N = 16 384 and 262 144 the same net measures err_build / err_ref = 0.7 ... 1.45,
+    # tests/test_gpu_timed_kernels.py), so it is taken over the minibatch AND over 4096 points of the same cube
+    # through the same weights
+    # ... and over eight more minibatches of the same size (the error of a 400-row gradient is dominated by its few
+    # worst rows -- activations reach exp(omega0^2 / 4 s0^2) = e per layer -- so single minibatches scatter by 2-3x)
+    ref_all, err_y_all = {}, 0.0
+    for nb in [4096] + [400] * 8:
+        cb = rng.uniform(-1, 1, (nb, 3)).astype(np.float32)
+        tb = (rng.random((nb, 1)) > 0.5).astype(np.float32)
+        ya64, ca64 = wo.wire_forward(P64, cb.astype(np.float64), 3, 20.0, 20.0, 10.0, keep=True)
+        ga64 = wo.wire_backward(P64, ca64, wo.mse_loss_and_grad(ya64, tb.astype(np.float64))[1], 3, 20.0, 20.0, 10.0)
+        ya32, ca32 = wo.wire_forward(P32, cb, 3, 20.0, 20.0, 10.0, keep=True)
+        ga32 = wo.wire_backward(P32, ca32, wo.mse_loss_and_grad(ya32, tb)[1], 3, 20.0, 20.0, 10.0)
+        for k in ga64:
+            ref_all[k] = max(ref_all.get(k, 0.0), relmax(wo.as_real_pairs(ga32[k]), wo.as_real_pairs(ga64[k])))
+        err_y_all = max(err_y_all, relmax(ya32, ya64))
+    worst = {}
     for b in range(0, npts, maxpoints):
         idx = perm[b:min(npts, b + maxpoints)]
         loss = tr.step(idx.to(DEV))                    # lr = 0: parameters stay put
@@ -502,8 +535,18 @@ def test_occupancy_style_minibatches_match_oracle():
             g = wo.as_real_pairs(g64[name]).astype(np.float64).ravel()
             mine = flat[off:off + g.size]
             ref_err = np.abs(wo.as_real_pairs(g32[name]).astype(np.float64).ravel() - g).max() / np.abs(g).max()
-            assert np.abs(mine - g).max() <= max(2e-4, 4 * ref_err) * np.abs(g).max() + 1e-9, name
+            if name == "net.4.bias":
+                final_bias_within_ref(mine, g, max(relmax(y32, y64), err_y_all), np.abs(y64).max(), 1,
+                                      f"occupancy batch {b} grad {name}",
+                                      resid_max=np.abs(y64 - vol[idx.numpy()]).max())
+            else:
+                worst.setdefault(name, [0.0, ref_all[name]])
+                worst[name][0] = max(worst[name][0], np.abs(mine - g).max() / np.abs(g).max())
+                worst[name][1] = max(worst[name][1], ref_err)
         np.testing.assert_allclose(tr.rec.cpu().numpy()[idx.numpy()], y64, atol=2e-4 * np.abs(y64).max())
+    # worst minibatch of the build against the worst of the reference arithmetic (same three minibatches + the sample)
+    for name, (eb, er) in worst.items():
+        within_ref(eb, er, f"occupancy minibatches grad {name}")
     full = tr.render(tile=333).cpu().numpy()
     y_all = wo.wire_forward(P64, coords_all.astype(np.float64), 3, 20.0, 20.0, 10.0)
     assert relmax(full, y_all) < 2e-4
@@ -685,5 +728,4 @@ def test_wire2d_layer_backward_matches_autograd(is_first):
 
     r64, r32 = ref(True), ref(False)
     for k in got:
-        ref_err = relmax(r32[k], r64[k])
-        assert relmax(got[k], r64[k]) <= 4 * ref_err + 3e-6, k
+        within_ref(relmax(got[k], r64[k]), relmax(r32[k], r64[k]), f"wire2d layer is_first={is_first} {k}")

@@ -1,0 +1,249 @@
+"""Parity protocol of SURVEY.md section 7 ON THE KERNELS bench.py TIMES.
+
+bench.py's step runs ``gemmx3_nt<EPI, 4, 2>`` (256-row tiles, selected at M >= 4096, lean hardware-transcendental
+epilogues), ``gemmx3_tn<2>`` with a 48-way row split, and ``final_fused_kernel``.  The fixtures of
+tests/golden hold <= 512 rows, which select the 128-row tiles.  Here every check runs at row counts and widths
+that select the timed code:
+
+ * per-layer, identical inputs (protocol step i): ``model.net[i](x)`` -> wire_gabor_fwd / wire_gabor_bwd, which
+   dispatch on the same family switch as wire_mlp_fwd / wire_mlp_bwd (wire_layer_api.hip), at n = 4133 rows
+   (tall tiles + a ragged last tile), K = 256, for the three GEMM families {x3, 3m, 4m}: forward <= 1e-5,
+   backward <= 2e-5 of the layer maximum, against the numpy fp64 oracle evaluated on the SAME (rounded) inputs;
+ * whole step (protocol step ii): ``FusedTrainer.step`` with lr = 0 at K = 256, L = 4, N = 16 384 and
+   N = 262 144 (BASELINE.json configs[1], the exact timed path: wire_train_fwd_bwd), every parameter gradient
+   against the fp64 oracle with the bound ``err_build <= 2 err_ref + 1e-6``.
+
+Reference arithmetic: modules/wire.py:88-93 (layer), :161-167 (net); siren.py:48-49; wire2d.py:56-67.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from _util import (family_ctx, final_bias_within_ref, params_np, relmax, wire_oracle_grads_chunked,
+                   within_ref)
+from oracle import wire_oracle as wo
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+N_TALL = 4096 + 37            # M >= 4096 -> 256-row tiles (wire_gemmx3.hip launch_gemmx3_nt), ragged last tile
+CFGS = {"baseline_w20_s30": (20.0, 30.0), "low_w7_s6": (7.0, 6.0)}
+
+
+def _wire_model(L, om, sc, hf=363, D=2, O=3, seed=0):
+    from wire_amd.modules import models
+    torch.manual_seed(seed)
+    return models.get_INR(nonlin="wire", in_features=D, out_features=O, hidden_features=hf, hidden_layers=L,
+                          first_omega_0=om, hidden_omega_0=om, scale=sc).to(DEV)
+
+
+def _grid_rows(n):
+    """n rows spread over the whole 512 x 512 grid of wire_image_denoise.py:63-66."""
+    c = wo.image_coords(512, 512)[::63]
+    assert c.shape[0] >= n
+    return np.ascontiguousarray(c[:n])
+
+
+@pytest.mark.parametrize("cfg", list(CFGS))
+@pytest.mark.parametrize("fam", ["x3", "3m", "4m"])
+def test_gabor_layers_identical_inputs_at_timed_shape(fam, cfg):
+    om, sc = CFGS[cfg]
+    model = _wire_model(2, om, sc)
+    assert model._arch["width"] == 256
+    P64 = wo.cast_params(params_np(model), True)
+    coords = _grid_rows(N_TALL)
+    rng = np.random.default_rng(7)
+    with family_ctx(fam):
+        x_np = coords                                   # layer 0 input: real coordinates
+        for i in range(3):
+            W, b = P64[f"net.{i}.linear.weight"], P64[f"net.{i}.linear.bias"]
+            lin64 = x_np.astype(W.dtype) @ W.T + b      # the oracle on the SAME rounded input
+            out64 = wo.gabor_act(lin64, om, sc)
+            x = torch.tensor(x_np, device=DEV, requires_grad=(i > 0))
+            model.zero_grad()
+            out = model.net[i](x)
+            assert out.dtype == torch.complex64 and tuple(out.shape) == (N_TALL, 256)
+            e_fwd = relmax(out.detach().cpu().numpy(), out64)
+            assert e_fwd <= 1e-5, f"{fam} {cfg} layer {i} forward {e_fwd:.2e}"
+            # backward of this layer alone
+            g = (rng.standard_normal(out64.shape) + 1j * rng.standard_normal(out64.shape)).astype(np.complex64)
+            out.backward(torch.tensor(g, device=DEV))
+            torch.cuda.synchronize()
+            gl = wo.gabor_act_grad(g.astype(np.complex128), lin64, out64, om, sc)
+            lw = model.net[i].linear
+            if i == 0:
+                e_w = relmax(lw.weight.grad.cpu().numpy(), gl.T @ x_np.astype(np.float64))
+                e_x = 0.0
+            else:
+                e_w = relmax(lw.weight.grad.cpu().numpy(), gl.T @ np.conj(x_np.astype(np.complex128)))
+                e_x = relmax(x.grad.cpu().numpy(), gl @ np.conj(W))
+            e_b = relmax(lw.bias.grad.cpu().numpy(), gl.sum(0))
+            assert max(e_w, e_x, e_b) <= 2e-5, f"{fam} {cfg} layer {i} backward W {e_w:.2e} x {e_x:.2e} b {e_b:.2e}"
+            print(f"{fam} {cfg} layer {i}: fwd {e_fwd:.2e}  gW {e_w:.2e}  gx {e_x:.2e}  gb {e_b:.2e}")
+            x_np = out64.astype(np.complex64)           # identical (rounded) input for the next layer
+
+
+@pytest.mark.parametrize("fam", ["x3", "4m"])
+def test_gabor_fwd_lin_out(fam):
+    """wire_gabor_fwd's optional pre-activation output (SURVEY 8(b)(1) ``lin_out``): complex64 for a hidden layer,
+    float32 for is_first."""
+    from wire_amd import _lib
+    om, sc = 7.0, 6.0
+    model = _wire_model(1, om, sc, hf=128)
+    K = model._arch["width"]
+    P64 = wo.cast_params(params_np(model), True)
+    n = 777
+    rng = np.random.default_rng(1)
+    with family_ctx(fam) as L:
+        s = torch.cuda.current_stream().cuda_stream
+        for is_first in (1, 0):
+            i = 0 if is_first else 1
+            fin = 2 if is_first else K
+            W, b = P64[f"net.{i}.linear.weight"], P64[f"net.{i}.linear.bias"]
+            if is_first:
+                x_np = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+            else:
+                x_np = (0.2 * (rng.standard_normal((n, K)) + 1j * rng.standard_normal((n, K)))).astype(np.complex64)
+            lin64 = x_np.astype(W.dtype) @ W.T + b
+            x = torch.tensor(x_np, device=DEV)
+            lw = model.net[i].linear
+            ws_bytes = _lib.check(L.wire_layer_ws_bytes(n, fin, K))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+            act = torch.empty(n, K, dtype=torch.complex64, device=DEV)
+            lin = torch.empty(n, K, dtype=torch.float32 if is_first else torch.complex64, device=DEV)
+            _lib.check(L.wire_gabor_fwd(s, x.data_ptr(), lw.weight.detach().data_ptr(), lw.bias.detach().data_ptr(),
+                                        om, sc, n, fin, K, is_first, lin.data_ptr(), act.data_ptr(), ws.data_ptr(),
+                                        ws_bytes), "wire_gabor_fwd")
+            torch.cuda.synchronize()
+            assert relmax(lin.cpu().numpy(), lin64) <= 2e-6
+            assert relmax(act.cpu().numpy(), wo.gabor_act(lin64, om, sc)) <= 1e-5
+
+
+@pytest.mark.parametrize("kind,om,sc", [("siren", 30.0, 10.0), ("gauss", 30.0, 10.0), ("relu", 30.0, 10.0)])
+@pytest.mark.parametrize("fam", ["x3", "4m"])
+def test_real_layers_identical_inputs_at_timed_shape(fam, kind, om, sc):
+    """SineLayer / GaussLayer / ReLULayer (modules/siren.py:48-49, gauss.py:27-28, relu.py:28-29), K = 256,
+    n = 4133: the layer GEMMs of BASELINE.json configs[4] on the family the sweep times."""
+    from wire_amd.modules import models
+    torch.manual_seed(0)
+    model = models.get_INR(nonlin=kind, in_features=2, out_features=3, hidden_features=256, hidden_layers=1,
+                           first_omega_0=om, hidden_omega_0=om, scale=sc).to(DEV)
+    P64 = wo.cast_params(params_np(model), True)
+    rng = np.random.default_rng(3)
+    W, b = P64["net.1.linear.weight"], P64["net.1.linear.bias"]
+    x_np = rng.uniform(-1, 1, (N_TALL, 256)).astype(np.float32) * (0.2 if kind == "gauss" else 1.0)
+    lin64 = x_np.astype(np.float64) @ W.T + b
+    out64 = wo.real_act(kind, lin64, om, sc)
+    with family_ctx(fam):
+        x = torch.tensor(x_np, device=DEV, requires_grad=True)
+        out = model.net[1](x)
+        assert relmax(out.detach().cpu().numpy(), out64) <= 1e-5
+        g = rng.standard_normal(out64.shape).astype(np.float32)
+        out.backward(torch.tensor(g, device=DEV))
+        torch.cuda.synchronize()
+    gl = wo.real_act_grad(kind, g.astype(np.float64), lin64, out64, om, sc)
+    if kind == "relu":
+        # the gradient of relu is discontinuous at lin = 0: rows whose fp32 lin has the other sign than the
+        # fp64 one cannot agree; compare with the mask taken from lin's sign where |lin| is not round-off
+        safe = np.abs(lin64) > 1e-5
+        gl = gl * safe
+        g_t = torch.tensor(g * safe, device=DEV)
+        with family_ctx(fam):
+            x = torch.tensor(x_np, device=DEV, requires_grad=True)
+            model.zero_grad()
+            model.net[1](x).backward(g_t)
+            torch.cuda.synchronize()
+    assert relmax(x.grad.cpu().numpy(), gl @ W) <= 2e-5
+    assert relmax(model.net[1].linear.weight.grad.cpu().numpy(), gl.T @ x_np.astype(np.float64)) <= 2e-5
+    assert relmax(model.net[1].linear.bias.grad.cpu().numpy(), gl.sum(0)) <= 2e-5
+
+
+@pytest.mark.parametrize("fam", ["x3", "4m"])
+def test_wire2d_layer_at_timed_shape(fam):
+    """ComplexGaborLayer2D (modules/wire2d.py:56-67), K2 = 128, n = 4133, against eager fp64 autograd of the
+    oracle's restatement (oracle/torch_ref.gabor2d)."""
+    from oracle import torch_ref
+    from wire_amd.modules.wire2d import ComplexGaborLayer2D
+    import torch.nn.functional as F
+    torch.manual_seed(5)
+    n, fin, fout, om, sc = N_TALL, 128, 128, 10.0, 10.0
+    layer = ComplexGaborLayer2D(fin, fout, is_first=False, omega0=om, sigma0=sc).to(DEV)
+    rng = np.random.default_rng(9)
+    x_np = (0.1 * (rng.standard_normal((n, fin)) + 1j * rng.standard_normal((n, fin)))).astype(np.complex64)
+    g_np = (rng.standard_normal((n, fout)) + 1j * rng.standard_normal((n, fout))).astype(np.complex64)
+    with family_ctx(fam):
+        x = torch.tensor(x_np, device=DEV, requires_grad=True)
+        out = layer(x)
+        out.backward(torch.tensor(g_np, device=DEV))
+        torch.cuda.synchronize()
+    got = {"W": layer.linear.weight.grad, "b": layer.linear.bias.grad, "V": layer.scale_orth.weight.grad,
+           "c": layer.scale_orth.bias.grad, "x": x.grad, "out": out.detach()}
+    got = {k: v.cpu().numpy() for k, v in got.items()}
+    cd = torch.complex128
+    W = layer.linear.weight.detach().cpu().to(cd).requires_grad_(True)
+    b = layer.linear.bias.detach().cpu().to(cd).requires_grad_(True)
+    V = layer.scale_orth.weight.detach().cpu().to(cd).requires_grad_(True)
+    c = layer.scale_orth.bias.detach().cpu().to(cd).requires_grad_(True)
+    xx = torch.tensor(x_np).to(cd).requires_grad_(True)
+    o = torch_ref.gabor2d(F.linear(xx, W, b), F.linear(xx, V, c), om, sc)
+    gg = torch.tensor(g_np).to(cd)
+    (o.real * gg.real + o.imag * gg.imag).sum().backward()
+    ref = {"W": W.grad, "b": b.grad, "V": V.grad, "c": c.grad, "x": xx.grad, "out": o.detach()}
+    assert relmax(got["out"], ref["out"].numpy()) <= 1e-5
+    for k in ("W", "b", "V", "c", "x"):
+        assert relmax(got[k], ref[k].numpy()) <= 2e-5, k
+
+
+# ---------------------------------------------------------------------------
+# the exact timed path: FusedTrainer.step -> wire_train_fwd_bwd at K = 256, L = 4
+# ---------------------------------------------------------------------------
+STEP_CASES = {
+    # name: (grid, hidden_features, L, O, omega0, sigma0)
+    "img16k_low_w7_s6": ((128, 128), 363, 4, 3, 7.0, 6.0),
+    "img16k_baseline_w20_s30": ((128, 128), 363, 4, 3, 20.0, 30.0),
+    "img262k_baseline_w20_s30": ((512, 512), 363, 4, 3, 20.0, 30.0),           # BASELINE.json configs[1]
+    "vol16k_occupancy_3x300_w20_s10": ((32, 32, 16), 300, 3, 1, 20.0, 10.0),   # wire_occupancy.py:43-44,89-91
+    "vol262k_occupancy_4x363_w20_s10": ((64, 64, 64), 363, 4, 1, 20.0, 10.0),  # BASELINE.json configs[2], 1 GPU's share
+}
+
+
+@pytest.mark.parametrize("case", list(STEP_CASES))
+def test_fused_trainer_step_gradients_vs_fp64_oracle(case):
+    """One FusedTrainer.step (lr = 0, a random permutation of the whole grid as the batch -- wire_image_denoise.py:
+    142-157, wire_occupancy.py:137-158) at the bench's architecture.  N = 16 384 and 262 144 rows run
+    gemmx3_nt<.,4,2>, final_fused_kernel and the row-split gemmx3_tn exactly as bench.py does.  Output, loss and
+    EVERY parameter gradient against the numpy fp64 oracle on the same weights; yardstick = the same oracle in
+    fp32 (the reference arithmetic's own round-off): err_build <= 2 err_ref + 1e-6."""
+    from wire_amd.trainer import FusedTrainer
+    grid, hf, Ln, On, om, sc = STEP_CASES[case]
+    N = int(np.prod(grid))
+    model = _wire_model(Ln, om, sc, hf=hf, D=len(grid), O=On)
+    g = torch.Generator().manual_seed(11)
+    target = torch.rand(N, On, generator=g)
+    perm = torch.randperm(N, generator=g)
+    three_d = len(grid) == 3
+    tr = FusedTrainer(model, grid, target, lr=0.0, keep_rec=True, coords_style="numpy" if three_d else "torch")
+    loss = tr.step(perm.to(DEV))
+    torch.cuda.synchronize()
+    P = params_np(model)
+    coords_all = wo.volume_coords(*grid) if three_d else wo.image_coords(*grid)
+    coords = coords_all[perm.numpy()]
+    tgt = target.numpy()[perm.numpy()]
+    y64, l64, g64 = wire_oracle_grads_chunked(P, coords, tgt, Ln, om, om, sc, double=True)
+    y32, l32, g32 = wire_oracle_grads_chunked(P, coords, tgt, Ln, om, om, sc, double=False)
+    tag = f"step[{case}]"
+    err_y_ref = relmax(y32, y64)
+    within_ref(relmax(tr.rec.cpu().numpy()[perm.numpy()], y64), err_y_ref, tag + " y")
+    assert abs(float(loss.item()) - l64) <= (2 * abs(l32 - l64) / l64 + 1e-5) * l64
+    flat = tr.flat_grad.cpu().numpy()
+    names = [k for k in model.state_dict().keys() if "omega_0" not in k and "scale_0" not in k]
+    for name, off in zip(names, tr.offsets):
+        ref = wo.as_real_pairs(g64[name]).astype(np.float64).ravel()
+        ref32 = wo.as_real_pairs(g32[name]).astype(np.float64).ravel()
+        mine = flat[off:off + ref.size]
+        if name == f"net.{Ln + 1}.bias":
+            final_bias_within_ref(mine, ref, err_y_ref, np.abs(y64).max(), On, f"{tag} grad {name}",
+                                  resid_max=np.abs(y64 - tgt).max())
+        else:
+            within_ref(relmax(mine, ref), relmax(ref32, ref), f"{tag} grad {name}")

@@ -1,0 +1,10 @@
+#!/bin/bash
+# builds build/gemm_glds_tune (A/B of the split-bf16 NT GEMM editions); run from the repo root
+set -e
+mkdir -p build
+make -C wire_amd/csrc -j4 >/dev/null
+# the LDS-DMA kernels once more with their ablation switches compiled in (harness only)
+hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -DWIRE_ABLATE_G -c wire_amd/csrc/wire_gemmx3g.hip -o build/wire_gemmx3g_abl.o
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -c tools/gemm_glds_tune.hip -o build/gemm_glds_tune.o
+hipcc --offload-arch=gfx950 build/gemm_glds_tune.o build/csrc/wire_gemm.o build/csrc/wire_gemm3m.o build/csrc/wire_gemmx3.o \
+      build/wire_gemmx3g_abl.o -o build/gemm_glds_tune

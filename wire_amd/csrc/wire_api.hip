@@ -103,6 +103,11 @@ static int env_flag(const char* name, int dflt) {
 }
 // every net: split-bf16 GEMMs on the bf16 MFMA (wire_gemmx3.hip); overrides complex_3m
 static int g_split_bf16 = env_flag("WIRE_SPLIT_BF16", 1);
+// family the flags select for a net kind (wire_layer_api.hip): 2 split-bf16, 1 complex 3M (wire only), 0 4M
+int wire_family_(int kind) {
+  if (g_split_bf16) return 2;
+  return (kind == WIRE_KIND_WIRE && g_complex_3m) ? 1 : 0;
+}
 extern "C" int wire_tune_get(const char* key) {
   if (!key) return fail(WIRE_ERR_ARG, "null key");
   if (!strcmp(key, "complex_3m")) return g_complex_3m;
@@ -599,6 +604,14 @@ extern "C" int wire_coords_from_index(void* stream, const int64_t* idx, int64_t 
     return fail(WIRE_ERR_ARG, "bad argument to wire_coords_from_index");
   ProfScope ps((hipStream_t)stream, 3, 0);
   HIPCHK(launch_coords((hipStream_t)stream, idx, first, n, tx, W, ty, H, tz, T, coords));
+  return WIRE_OK;
+}
+extern "C" int wire_perm_indices(void* stream, uint64_t seed, int64_t n_total, int64_t first, int64_t count,
+                                 int64_t* idx_out) {
+  if (n_total < 1 || first < 0 || count < 0 || first + count > n_total || (count > 0 && !idx_out))
+    return fail(WIRE_ERR_ARG, "bad argument to wire_perm_indices");
+  ProfScope ps((hipStream_t)stream, 3, 0);
+  HIPCHK(launch_perm_indices((hipStream_t)stream, seed, n_total, first, count, idx_out));
   return WIRE_OK;
 }
 extern "C" int wire_mse_grad(void* stream, const float* y, const float* target, const int64_t* idx,

@@ -35,6 +35,7 @@ struct GemmEpiParams {
   int D = 0;
   int ldu = 0;
   int wide = 0;                  // set by the launcher when 32-bit byte offsets could overflow
+  int stagger = 0, stagger_lo = 0, stagger_hi = 0;   // wire_gemmx3g.hip: late start (100 MHz ticks) of blocks [lo, hi)
 #ifdef WIRE_ABLATE
   int ablate = 0;                // tools/gemm_tune only: 1 no global loads, 2 no LDS writes, 4 no barrier
 #endif
@@ -76,3 +77,10 @@ int gemmx3_tune_set(const char* key, int value);
 int gemmx3_tn_splits(int64_t n, int Pm, int Pn, int max_splits);
 hipError_t launch_gemmx3_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n,
                             int Pm, int Pn, int splits, float* slab, float* bslab);
+
+// ---- LDS-DMA edition of the split-bf16 NT GEMM for large batches (wire_gemmx3g.hip); same operands and image
+bool gemmx3g_handles(int epi, int64_t M);
+int gemmx3g_tune_set(const char* key, int value);
+int gemmx3g_mode();
+hipError_t launch_gemmx3g_nt(hipStream_t s, int epi, const float* A, int lda, const void* Bx3, int64_t M,
+                             int Nc, int Kd, const GemmEpiParams& ep);

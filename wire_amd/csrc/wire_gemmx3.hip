@@ -84,7 +84,8 @@ WIRE_DEVINL int x3_off(int row, int half) { return row * 32 + ((half ^ ((row >> 
 
 // ---------------------------------------------------------------------------
 // weights: fp32 image Bt[Nc][ldb] -> stage-major split image
-//   Bx3[col tile ct][stage kt][plane p][col c (128)][16 k]   (bf16)
+//   Bx3[col tile ct][stage kt][plane p][col c (128)][16 k]   (bf16; the two 8-k halves of a column swapped when
+//   bit 3 of c is set: the LDS bank swizzle)
 // so that the 4 KB of one (tile, stage, plane) are contiguous: thread t of the GEMM loads bytes [16 t, 16 t + 16).
 // ---------------------------------------------------------------------------
 __global__ void x3_split_b_kernel(const float* __restrict__ Bt, int ldb, int Nc, int Kd, int nk,
@@ -96,8 +97,12 @@ __global__ void x3_split_b_kernel(const float* __restrict__ Bt, int ldb, int Nc,
   if (j < Nc) { x0 = Bt[(size_t)j * ldb + k2]; x1 = Bt[(size_t)j * ldb + k2 + 1]; }
   const Split2 sp = split2(x0, x1);
   const unsigned H = sp.h, Mi = sp.m, L = sp.l;
+  // the bank swizzle of the LDS image (x3_off: 16-byte half XOR bit 3 of the column) is baked in here, so that a
+  // plane of a stage is copied to LDS as it lies -- by 16-byte register stores at byte 16 t (gemmx3_nt_kernel) or
+  // by LDS-DMA (wire_gemmx3g.hip)
   const int ct = j >> 7, c = j & 127, kt = k2 >> 4, kk = k2 & 15;
-  const size_t base = ((size_t)(ct * nk + kt) * 3 * 128 + c) * 16 + kk;
+  const int kk_sw = (((kk >> 3) ^ ((c >> 3) & 1)) << 3) | (kk & 7);
+  const size_t base = ((size_t)(ct * nk + kt) * 3 * 128 + c) * 16 + kk_sw;
   *reinterpret_cast<unsigned*>(Bx3 + base) = H;
   *reinterpret_cast<unsigned*>(Bx3 + base + 128 * 16) = Mi;
   *reinterpret_cast<unsigned*>(Bx3 + base + 2 * 128 * 16) = L;
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(256, (MT * WN > 4 ? 2 : 3)) void gemmx3_nt_kernel(
       *reinterpret_cast<u32x4*>(d + 2 * APLANE) = u32x4{s0.l, s1.l, s2.l, s3.l};
     }
 #pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(S + 3 * APLANE + p * X3_PLANE + st_off) = R.b[p];
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(S + 3 * APLANE + p * X3_PLANE + tid * 16) = R.b[p];
   };
 #ifdef WIRE_ABLATE
   // diagnostic build only (tools/gemm_tune): stamp the shader clock and the 100 MHz reference around the main loop
@@ -331,12 +336,13 @@ static int g_x3_tall = x3_env("WIRE_X3_TALL", 1);
 int gemmx3_tune_set(const char* key, int value) {
   if (!strcmp(key, "x3_tall") && (value == 0 || value == 1)) { g_x3_tall = value; return 0; }
   if (!strcmp(key, "x3_tn_tall") && (value == 0 || value == 1)) { g_x3_tn_tall = value; return 0; }
-  return -1;
+  return gemmx3g_tune_set(key, value);
 }
 
 hipError_t launch_gemmx3_nt(hipStream_t s, int epi, const float* A, int lda, const void* Bx3, int64_t M,
                             int Nc, int Kd, const GemmEpiParams& ep_in) {
   if (M <= 0) return hipSuccess;
+  if (gemmx3g_handles(epi, M)) return launch_gemmx3g_nt(s, epi, A, lda, Bx3, M, Nc, Kd, ep_in);   // LDS-DMA edition
   if ((Nc & 63) || (Kd & 31) || (lda & 3) || M > 0x7fffff00LL) return hipErrorInvalidValue;
   // the lean Gabor epilogues share one 32-bit byte offset between their buffers
   GemmEpiParams ep = ep_in;

@@ -1,0 +1,309 @@
+// wire_gemmx3g.hip -- split-bf16 NT GEMM of the WIRE hot path, LDS-DMA edition (large batches).
+//
+// Same arithmetic as wire_gemmx3.hip (every fp32 operand = h + m + l in bf16, six partial products on
+// v_mfma_f32_32x32x16_bf16, fp32 accumulate), same operands (fp32 blocked-planar activation rows, the pre-split
+// stage-major weight image), same epilogues (wire_gemm_epi.h).  What differs is how a stage reaches the matrix
+// cores.  In wire_gemmx3.hip a loader pulls the fp32 rows into registers, splits them and stores three bf16
+// planes to LDS: per wave and 16-deep stage 7 global_load_dwordx4, 88 vector ops and 9 ds_write_b128 -- and on
+// gfx950 those register-file round trips do NOT hide beside the MFMAs (tools/mfma_bf16_probe.hip: one
+// ds_write_b128 per MFMA costs 58-72 cycles of the stream, one global_load_dwordx4 about 32).
+// Here
+//   * both operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR destination, no ds_write).  The
+//     activation rows stay fp32 in LDS (64 B per row and stage instead of 96 B of planes); the weight planes are
+//     copied as they lie (the bank swizzle is baked into the image by x3_split_b_kernel; for the activations it is
+//     applied on the per-lane SOURCE address, the LDS image of a 1-KiB piece being lane-linear by construction);
+//   * the split h + m + l happens on the A FRAGMENT, in registers, right before its MFMAs: a wave owns 64 rows x
+//     all 128 columns of the 256 x 128 tile (4 waves stacked in M), so every row is split by exactly one wave --
+//     the same 88 vector ops per wave and stage as the loader needed, but no store and no second pass over LDS;
+//   * double-buffered 28 KB stages (56 KB -> 2 workgroups per CU, whose phases drift apart and fill each other's
+//     gaps), ONE raw s_barrier per stage, the DMA of stage t+1 in flight under the MFMAs of stage t.
+//
+// Replaces the ATen complex addmm / mm of modules/wire.py:89 and of its autograd backward at M >= 4096.
+#include <cstdlib>
+#include <cstring>
+
+#include "wire_dev.h"
+#include "wire_gemm.h"
+#include "wire_gemm_epi.h"
+
+typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gbf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
+
+#define G_BK 16
+
+WIRE_DEVINL unsigned g_cvt_pk_bf16(float a, float b) {
+  const gbf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+WIRE_DEVINL float g_bf16_lo(unsigned packed) {
+  unsigned r;
+  asm("v_lshlrev_b32 %0, 16, %1" : "=v"(r) : "v"(packed));
+  return __uint_as_float(r);
+}
+// exact three-way split of two floats into packed bf16 pairs (as split2 of wire_gemmx3.hip)
+WIRE_DEVINL void g_split2(float x0, float x1, unsigned& H, unsigned& Mi, unsigned& L) {
+  H = g_cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - g_bf16_lo(H), r1 = x1 - __uint_as_float(H & 0xffff0000u);
+  Mi = g_cvt_pk_bf16(r0, r1);
+  const float q0 = r0 - g_bf16_lo(Mi), q1 = r1 - __uint_as_float(Mi & 0xffff0000u);
+  L = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+}
+
+#define G_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+// one 1-KiB piece: lane i's 16 bytes land at lds_piece + 16 i
+WIRE_DEVINL void g_dma16(const void* gsrc, unsigned char* lds_piece) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)gsrc,
+      (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
+}
+
+// MT x NT 32-blocks per wave, WM x WNW waves; NSTAGE LDS buffers (prefetch distance NSTAGE - 1)
+template <int EPI, int MT, int NT, int WM, int WNW, int NSTAGE>
+__global__ __launch_bounds__(64 * WM * WNW, 2) void gemmx3g_nt_kernel(
+    const float* __restrict__ A, int lda, const unsigned short* __restrict__ Bx3, int M, int Nc, int Kd,
+    int tiles_m, int tiles_n, int tiles128, GemmEpiParams ep) {
+  constexpr int NW = WM * WNW;
+  constexpr int TBM = WM * MT * 32, TBN = WNW * NT * 32;
+  constexpr int A_BYTES = TBM * 64;                  // fp32 rows: 16 k x 4 B
+  constexpr int B_PLANE = TBN * 32;                  // bf16 plane: 16 k x 2 B per column
+  constexpr int STAGE = A_BYTES + 3 * B_PLANE;
+  constexpr int A_PIECES = TBM / 16, B_PPP = TBN / 32, PIECES = A_PIECES + 3 * B_PPP;
+  static_assert(PIECES % NW == 0, "every wave moves the same number of pieces (counted vmcnt)");
+  static_assert(TBN % 128 == 0, "the weight image is cut in 128-column tiles");
+  constexpr int PPW = PIECES / NW;
+  constexpr int D = NSTAGE - 1;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / WNW, wave_n = wave % WNW;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // XCD-aware tile order (as gemmx3_nt_kernel): the column tiles of one row tile run on one L2
+  const int b = blockIdx.x;
+  const int xcd = b & 7, idx = b >> 3;
+  const int ct = idx % tiles_n;
+  const int rt = (idx / tiles_n) * 8 + xcd;
+  if (rt >= tiles_m) return;
+  const int m_base = rt * TBM, n_base = ct * TBN;
+  const int nk = Kd / G_BK;
+  // experiment: de-phase the two co-resident workgroups of a CU (the second slot of the first generation starts
+  // late), so that the HBM burst of one's epilogue meets the other's main loop instead of its epilogue
+  if (ep.stagger > 0 && b >= ep.stagger_lo && b < ep.stagger_hi) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ep.stagger) __builtin_amdgcn_s_sleep(32);
+  }
+
+  // ---- DMA plan: piece q = wave + NW j.  A piece = 16 rows x 64 B, lane i -> row 16 a + (i >> 2), LDS chunk
+  // i & 3 holding global chunk (i & 3) ^ ((row >> 2) & 3); B piece = 32 columns x 32 B of one plane, a straight copy.
+  const char* src[PPW];
+  int adv[PPW], loff[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int q = wave + NW * j;                     // wave-uniform
+    if (q < A_PIECES) {
+      const int r = 16 * q + (lane >> 2);
+      const int c = (lane & 3) ^ ((r >> 2) & 3);
+      int row = m_base + r;
+      row = row < M ? row : M - 1;
+      src[j] = reinterpret_cast<const char*>(A + (size_t)row * lda + c * 4);
+      adv[j] = G_BK * 4;
+      loff[j] = q * 1024;
+    } else {
+      const int bq = q - A_PIECES;
+      const int p = bq / B_PPP, cb = bq % B_PPP;
+      int t128 = ct * (TBN / 128) + (cb >> 2);
+      t128 = t128 < tiles128 ? t128 : tiles128 - 1;  // ragged last tile: re-read a valid one (its waves are dead)
+      src[j] = reinterpret_cast<const char*>(Bx3 + ((size_t)t128 * nk * 3 + p) * (128 * 16) + (cb & 3) * (32 * 16) +
+                                             lane * 8);
+      adv[j] = 3 * 128 * 16 * 2;
+      loff[j] = A_BYTES + p * B_PLANE + cb * 1024;
+    }
+  }
+  auto issue = [&](int kt, int buf) {
+    unsigned char* S = smem + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) g_dma16(src[j] + (size_t)kt * adv[j], S + loff[j]);
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses inside a stage
+  int a_rd[MT][2], b_rd[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int rr = wave_m * (MT * 32) + i * 32 + l31;
+    const int sw = (rr >> 2) & 3;
+    a_rd[i][0] = rr * 64 + (((2 * h) ^ sw) << 4);
+    a_rd[i][1] = rr * 64 + (((2 * h + 1) ^ sw) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int cc = wave_n * (NT * 32) + j * 32 + l31;
+    b_rd[j] = A_BYTES + cc * 32 + ((h ^ ((cc >> 3) & 1)) << 4);
+  }
+
+  // ---- prologue: D stages in flight, the first one landed
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < nk) issue(s, s);
+  if (D >= 2 && nk >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * PPW) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int buf = 0, pbuf = D % NSTAGE;
+  f32x4 araw[MT][2];
+  gbf16x8 bf[NT][3];
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* S = smem + buf * STAGE;
+    // fragment reads of this stage first: the compiler orders every LDS read behind ALL outstanding LDS-DMA it can
+    // see, so the DMA of the next stage is issued after them
+#ifdef WIRE_ABLATE_G
+    if (!(ep.stagger_lo & 4) || kt == 0) {
+#endif
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      araw[i][0] = *reinterpret_cast<const f32x4*>(S + a_rd[i][0]);
+      araw[i][1] = *reinterpret_cast<const f32x4*>(S + a_rd[i][1]);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const gbf16x8*>(S + p * B_PLANE + b_rd[j]);
+#ifdef WIRE_ABLATE_G
+    }
+#endif
+    // (the buffer being refilled was read one stage ago; every wave has passed that stage's barrier)
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef WIRE_ABLATE_G
+    if (!(ep.stagger_lo & 1))
+#endif
+    if (kt + D < nk) issue(kt + D, pbuf);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      unsigned H[4], Mi[4], L[4];
+      g_split2(araw[i][0][0], araw[i][0][1], H[0], Mi[0], L[0]);
+      g_split2(araw[i][0][2], araw[i][0][3], H[1], Mi[1], L[1]);
+      g_split2(araw[i][1][0], araw[i][1][1], H[2], Mi[2], L[2]);
+      g_split2(araw[i][1][2], araw[i][1][3], H[3], Mi[3], L[3]);
+      const gbf16x8 ah = __builtin_bit_cast(gbf16x8, gu32x4{H[0], H[1], H[2], H[3]});
+      const gbf16x8 am = __builtin_bit_cast(gbf16x8, gu32x4{Mi[0], Mi[1], Mi[2], Mi[3]});
+      const gbf16x8 al = __builtin_bit_cast(gbf16x8, gu32x4{L[0], L[1], L[2], L[3]});
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        // small terms first: h*l, l*h, m*m, h*m, m*h, h*h
+        G_MFMA(ah, bf[j][2], acc[i][j]);
+        G_MFMA(al, bf[j][0], acc[i][j]);
+        G_MFMA(am, bf[j][1], acc[i][j]);
+        G_MFMA(ah, bf[j][1], acc[i][j]);
+        G_MFMA(am, bf[j][0], acc[i][j]);
+        G_MFMA(ah, bf[j][0], acc[i][j]);
+      }
+    }
+    // the split of row block i + 1 rides in the shadow of the MFMAs of row block i: 2 vector ops after every MFMA
+    if (MT > 1) {
+#pragma unroll
+      for (int g = 0; g < (MT - 1) * NT * 6; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+    }
+    // stage kt + 1 must have landed before anyone reads it; later stages stay in flight.  (sched_barrier: the
+    // MFMAs touch no memory, so nothing else keeps the compiler from hoisting the wait and the barrier above them)
+    __builtin_amdgcn_sched_barrier(0);
+    if (D >= 2) {
+      if (kt + D < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * PPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+    pbuf = pbuf + 1 == NSTAGE ? 0 : pbuf + 1;
+  }
+  const bool wave_live = (n_base + wave_n * (NT * 32)) < Nc;
+  if (!wave_live) return;
+#ifdef WIRE_ABLATE_G
+  if (ep.stagger_lo & 2) {      // no epilogue: keep the accumulators alive with one conditional store
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v += acc[i][j][r];
+    if (v == 12345.678f) ep.o0[0] = v;
+    return;
+  }
+#endif
+  gemm_epilogue<EPI, MT, NT, true>(acc, ep, M, m_base + wave_m * (MT * 32), n_base + wave_n * (NT * 32), l31, h);
+}
+
+template <int EPI, int MT, int NT, int WM, int WNW, int NSTAGE>
+static hipError_t launchx3g_t(hipStream_t s, const float* A, int lda, const void* Bx3, int64_t M, int Nc, int Kd,
+                              const GemmEpiParams& ep) {
+  constexpr int TBM = WM * MT * 32, TBN = WNW * NT * 32;
+  const int tiles_m = (int)((M + TBM - 1) / TBM);
+  const int tiles_n = (Nc + TBN - 1) / TBN;
+  const int tiles128 = (Nc + 127) / 128;
+  const int tiles_m_pad = (tiles_m + 7) & ~7;
+  hipLaunchKernelGGL((gemmx3g_nt_kernel<EPI, MT, NT, WM, WNW, NSTAGE>), dim3((unsigned)(tiles_m_pad * tiles_n)),
+                     dim3(64 * WM * WNW), 0, s, A, lda, (const unsigned short*)Bx3, (int)M, Nc, Kd, tiles_m, tiles_n,
+                     tiles128, ep);
+  return hipGetLastError();
+}
+
+static int x3g_env(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+// 0: off (wire_gemmx3.hip kernels), 1: 256 x 128 tile, 4 waves, 2 buffers (2 workgroups / CU),
+// 2: 256 x 256 tile, 8 waves, 3 buffers (1 workgroup / CU)
+static int g_x3_glds = x3g_env("WIRE_X3_GLDS", 0);
+static int g_x3_stagger = x3g_env("WIRE_X3_STAGGER", 0);          // ticks of the 100 MHz counter (100 = 1 us)
+static int g_x3_stagger_lo = x3g_env("WIRE_X3_STAGGER_LO", 256), g_x3_stagger_hi = x3g_env("WIRE_X3_STAGGER_HI", 512);
+int gemmx3g_tune_set(const char* key, int value) {
+  if (!strcmp(key, "x3_glds") && value >= 0 && value <= 2) { g_x3_glds = value; return 0; }
+  if (!strcmp(key, "x3_stagger") && value >= 0) { g_x3_stagger = value; return 0; }
+  if (!strcmp(key, "x3_stagger_lo") && value >= 0) { g_x3_stagger_lo = value; return 0; }
+  if (!strcmp(key, "x3_stagger_hi") && value >= 0) { g_x3_stagger_hi = value; return 0; }
+  return -1;
+}
+int gemmx3g_mode() { return g_x3_glds; }
+
+// true when this file has a kernel for the call (large batches of the Gabor / store epilogues)
+bool gemmx3g_handles(int epi, int64_t M) {
+  if (!g_x3_glds || M < 4096) return false;
+  return epi == EPI_STORE || epi == EPI_GABOR_FWD || epi == EPI_GABOR_BWD || epi == EPI_GABOR_BWD_FIRST;
+}
+
+hipError_t launch_gemmx3g_nt(hipStream_t s, int epi, const float* A, int lda, const void* Bx3, int64_t M, int Nc,
+                             int Kd, const GemmEpiParams& ep_in) {
+  if (M <= 0) return hipSuccess;
+  if ((Nc & 63) || (Kd & 31) || (lda & 3) || M > 0x7fffff00LL) return hipErrorInvalidValue;
+  GemmEpiParams ep = ep_in;
+  if ((epi == EPI_GABOR_FWD || epi == EPI_GABOR_BWD) && ep.ld0 != ep.ld1) ep.wide = 1;
+  if ((double)M * (double)(ep.ld1 > ep.ld0 ? ep.ld1 : ep.ld0) * 4.0 >= 4294967296.0) ep.wide = 1;
+  ep.stagger = g_x3_stagger; ep.stagger_lo = g_x3_stagger_lo; ep.stagger_hi = g_x3_stagger_hi;
+#define X3G_CASE(E)                                                                                  \
+  case E:                                                                                            \
+    return g_x3_glds == 2 ? launchx3g_t<E, 2, 4, 4, 2, 3>(s, A, lda, Bx3, M, Nc, Kd, ep)             \
+                          : launchx3g_t<E, 2, 4, 4, 1, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+  switch (epi) {
+    X3G_CASE(EPI_STORE)
+    X3G_CASE(EPI_GABOR_FWD)
+    X3G_CASE(EPI_GABOR_BWD)
+    X3G_CASE(EPI_GABOR_BWD_FIRST)
+    default: return hipErrorInvalidValue;
+  }
+#undef X3G_CASE
+}

@@ -7,11 +7,19 @@
 // of asking the caller to keep lin/act in a private layout.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "../../include/wire_hip.h"
 #include "wire_gemm.h"
 #include "wire_point.h"
 
 extern int wire_fail_(int code, const char* msg);   // wire_api.hip
+// GEMM family the tuning flags select (wire_api.hip): 2 = split-bf16 (wire_gemmx3.hip, every kind),
+// 1 = 3-multiplication complex fp32 MFMA (wire_gemm3m.hip, ComplexGaborLayer only), 0 = 4M fp32 MFMA.
+// The per-layer entry points run the SAME kernels as wire_mlp_fwd / wire_mlp_bwd, so the per-layer parity
+// tests (protocol step (i)) check the code the bench times.
+extern int wire_family_(int kind);
+enum { FAM_4M = 0, FAM_3M = 1, FAM_X3 = 2 };
 
 namespace {
 inline int rup(int v, int m) { return (v + m - 1) / m * m; }
@@ -19,14 +27,34 @@ inline int64_t rup64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 struct LayerWs {
   int Pin, Pout, S;
-  int64_t xb, lin, out, gact, glin, gxb, gu, btf, btd, bias, slab, bslab, fpw, fpb, crp, wf, bfr, total;
+  int64_t xb, lin, out, gact, glin, gxb, gu, btf, btd, bias, slab, bslab, fpw, fpb, crp, wf, bfr, btf_x3, btd_x3, total;
 };
+// weight-gradient row splits of a family (the workspace is sized for the largest: its size must not depend on
+// the tuning flags)
+inline int layer_splits(int fam, int64_t n, int Pout, int Pin) {
+  if (fam == FAM_X3) return gemmx3_tn_splits(n, Pout, Pin, 192);
+  if (fam == FAM_3M) return gemm3m_tn_splits(n, Pout / 2, Pin / 2, 64);
+  return gemm_tn_splits(n, Pout, Pin, 64);
+}
 LayerWs layer_ws(int64_t n, int in, int out) {
   LayerWs w{};
   w.Pin = rup(2 * in, 64);
   w.Pout = rup(2 * out, 64);
   const int Pmax = w.Pin > w.Pout ? w.Pin : w.Pout;
-  w.S = gemm_tn_splits(n, w.Pout, w.Pin, 64);
+  w.S = layer_splits(FAM_4M, n, w.Pout, w.Pin);
+  // weight-gradient slabs: room for every family, for the complex sizing and for the real layers' own
+  // (narrower rows split finer, so neither sizing dominates the other)
+  int64_t slab_f = 0, bslab_f = 0;
+  auto fit = [&](int Pm, int Pn) {
+    for (int fam = FAM_4M; fam <= FAM_X3; ++fam) {
+      const int64_t S = layer_splits(fam, n, Pm, Pn);
+      const int64_t sl = fam == FAM_3M ? S * 3 * (Pm / 2) * (Pn / 2) : S * Pm * Pn;
+      if (sl > slab_f) slab_f = sl;
+      if (S * Pm > bslab_f) bslab_f = S * Pm;
+    }
+  };
+  fit(w.Pout, w.Pin);
+  fit(rup(out, 64), rup(in, 64));
   int64_t off = 0;
   auto take = [&](int64_t cnt) { int64_t o = off; off += rup64(cnt, 64); return o; };
   w.xb = take(n * w.Pin);
@@ -39,16 +67,57 @@ LayerWs layer_ws(int64_t n, int in, int out) {
   w.btf = take((int64_t)w.Pout * w.Pin);
   w.btd = take((int64_t)w.Pout * w.Pin);
   w.bias = take(w.Pout);
-  w.slab = take((int64_t)w.S * w.Pout * w.Pin);
-  w.bslab = take((int64_t)w.S * w.Pout);
+  w.slab = take(slab_f);
+  w.bslab = take(bslab_f);
   w.fpw = take((int64_t)(final_bwd_blocks(n) + 32) * 8 * Pmax);
   w.fpb = take((int64_t)(final_bwd_blocks(n) + 32) * 8);
   w.crp = take((int64_t)(colreduce_blocks(n) + 32) * (w.Pout / 2) * 5);
   w.wf = take((int64_t)8 * Pmax);
   w.bfr = take(64);
+  w.btf_x3 = take(gemmx3_b_image_floats(w.Pout, w.Pin));
+  w.btd_x3 = take(gemmx3_b_image_floats(w.Pin, w.Pout));
   w.total = off;
   return w;
 }
+
+// One layer's GEMMs on the selected family.  All three take blocked rows (wire_dev.h) and leave the same
+// outputs; they differ in the weight image (pack_*) and in the slab format of the weight gradient.
+struct LayerGemm {
+  int fam;
+  // weights: W_ + btf / btd hold the fp32 images of the family, btf_x3 / btd_x3 the split images
+  hipError_t pack(hipStream_t s, int kind, const float* W, const float* b, const float* V, const float* c, int out,
+                  int in, int Pout_g, int Pin, float* btf, float* btd, float* bias, float* btf_x3,
+                  float* btd_x3) const {
+    if (fam == FAM_3M) return launch_pack3m(s, W, b, out, in, Pout_g / 2, Pin / 2, btf, btd, bias);
+    hipError_t e = launch_pack_hidden(s, kind, W, b, V, c, out, in, kind == NK_WIRE2D ? Pout_g / 2 : Pout_g, Pin,
+                                      btf, btd, bias);
+    if (e != hipSuccess || fam != FAM_X3) return e;
+    e = launch_x3_split_b(s, btf, Pin, Pout_g, Pin, btf_x3);
+    if (e != hipSuccess) return e;
+    return launch_x3_split_b(s, btd, Pout_g, Pin, Pout_g, btd_x3);
+  }
+  // C[n][Nc] = A[n][Kd] * image^T + epilogue; dgrad = true uses the transposed-conjugate image
+  hipError_t nt(hipStream_t s, int epi, const float* A, int64_t n, int Nc, int Kd, bool dgrad, const float* btf,
+                const float* btd, const float* btf_x3, const float* btd_x3, const GemmEpiParams& ep) const {
+    if (fam == FAM_X3) return launch_gemmx3_nt(s, epi, A, Kd, dgrad ? btd_x3 : btf_x3, n, Nc, Kd, ep);
+    if (fam == FAM_3M) return launch_gemm3m_nt(s, epi, A, Kd, dgrad ? btd : btf, Kd, n, Nc / 2, Kd / 2, ep);
+    return launch_gemm_nt(s, epi, A, Kd, dgrad ? btd : btf, Kd, n, Nc, Kd, ep);
+  }
+  hipError_t tn_reduce(hipStream_t s, int kind, const float* G, const float* Z, int64_t n, int Pm, int Pn, int out,
+                       int in, float* slab, float* bslab, float* gW, float* gb, float* gV, float* gc) const {
+    const int S = layer_splits(fam, n, Pm, Pn);
+    hipError_t e;
+    if (fam == FAM_3M) {
+      e = launch_gemm3m_tn(s, G, Pm, Z, Pn, n, Pm / 2, Pn / 2, S, slab, bslab);
+      if (e != hipSuccess) return e;
+      return launch_wgrad3m_reduce(s, slab, bslab, S, out, in, Pm / 2, Pn / 2, gW, gb);
+    }
+    e = fam == FAM_X3 ? launch_gemmx3_tn(s, G, Pm, Z, Pn, n, Pm, Pn, S, slab, bslab)
+                      : launch_gemm_tn(s, G, Pm, Z, Pn, n, Pm, Pn, S, slab, bslab);
+    if (e != hipSuccess) return e;
+    return launch_wgrad_reduce(s, kind, slab, bslab, S, out, in, Pm, Pn, gW, gb, gV, gc);
+  }
+};
 }  // namespace
 
 #define LCHK(expr)                                                   \
@@ -65,20 +134,24 @@ extern "C" int64_t wire_layer_ws_bytes(int64_t n, int in_features, int out_featu
 // forward into the workspace (lin, out blocked).  Shared by fwd and bwd.
 static int layer_forward_ws(hipStream_t s, const LayerWs& w, float* W_, const void* x, const void* Wt,
                             const void* b, float omega0, float scale0, int64_t n, int in, int out,
-                            int is_first) {
+                            int is_first, bool want_lin = false) {
   if (is_first) {
     if (in > 4) return wire_fail_(WIRE_ERR_ARG, "is_first layers support in_features <= 4");
+    // u = x W0^T + b0 is real: [n][Pout / 2] rows in W_ + w.lin when asked for
     LCHK(launch_first_fwd(s, NK_WIRE, (const float*)x, n, in, (const float*)Wt, (const float*)b,
-                          nullptr, nullptr, out, w.Pout, omega0, scale0, nullptr, W_ + w.out));
+                          nullptr, nullptr, out, w.Pout, omega0, scale0, want_lin ? W_ + w.lin : nullptr,
+                          W_ + w.out));
     return WIRE_OK;
   }
+  const LayerGemm g{wire_family_(WIRE_KIND_WIRE)};
   LCHK(launch_c64_to_blocked(s, (const float*)x, n, in, w.Pin, W_ + w.xb));
-  LCHK(launch_pack_hidden(s, NK_WIRE, (const float*)Wt, (const float*)b, nullptr, nullptr, out, in,
-                          w.Pout, w.Pin, W_ + w.btf, W_ + w.btd, W_ + w.bias));
+  LCHK(g.pack(s, NK_WIRE, (const float*)Wt, (const float*)b, nullptr, nullptr, out, in, w.Pout, w.Pin, W_ + w.btf,
+              W_ + w.btd, W_ + w.bias, W_ + w.btf_x3, W_ + w.btd_x3));
   GemmEpiParams ep;
   ep.bias = W_ + w.bias; ep.o0 = W_ + w.lin; ep.o1 = W_ + w.out; ep.ld0 = w.Pout; ep.ld1 = w.Pout;
   ep.omega = omega0; ep.scale = scale0; ep.kvalid = out;
-  LCHK(launch_gemm_nt(s, EPI_GABOR_FWD, W_ + w.xb, w.Pin, W_ + w.btf, w.Pin, n, w.Pout, w.Pin, ep));
+  LCHK(g.nt(s, EPI_GABOR_FWD, W_ + w.xb, n, w.Pout, w.Pin, false, W_ + w.btf, W_ + w.btd, W_ + w.btf_x3,
+            W_ + w.btd_x3, ep));
   return WIRE_OK;
 }
 
@@ -88,15 +161,20 @@ extern "C" int wire_gabor_fwd(void* stream, const void* x, const void* W, const 
                               void* ws, int64_t ws_bytes) {
   if (n < 0 || in_features < 1 || out_features < 1 || !x || !W || !b || !act_out || !ws)
     return wire_fail_(WIRE_ERR_ARG, "bad argument to wire_gabor_fwd");
-  if (lin_out) return wire_fail_(WIRE_ERR_ARG, "lin_out is not supported in ABI v1 (pass NULL)");
   if (n == 0) return WIRE_OK;
   const LayerWs w = layer_ws(n, in_features, out_features);
   if (ws_bytes < w.total * 4) return wire_fail_(WIRE_ERR_SIZE, "layer workspace too small");
   hipStream_t s = (hipStream_t)stream;
   float* W_ = (float*)ws;
-  if (int rc = layer_forward_ws(s, w, W_, x, W, b, omega0, scale0, n, in_features, out_features, is_first))
+  if (int rc = layer_forward_ws(s, w, W_, x, W, b, omega0, scale0, n, in_features, out_features, is_first,
+                                lin_out != nullptr))
     return rc;
   LCHK(launch_blocked_to_c64(s, W_ + w.out, n, out_features, w.Pout, (float*)act_out));
+  if (lin_out) {
+    // the pre-activation `lin` of modules/wire.py:89: complex64 [n][out], or float32 [n][out] for is_first
+    if (is_first) LCHK(launch_unpad_rows(s, W_ + w.lin, n, out_features, w.Pout / 2, (float*)lin_out));
+    else LCHK(launch_blocked_to_c64(s, W_ + w.lin, n, out_features, w.Pout, (float*)lin_out));
+  }
   return WIRE_OK;
 }
 
@@ -124,15 +202,15 @@ extern "C" int wire_gabor_bwd(void* stream, const void* g_act, const void* x, co
   }
   LCHK(launch_gabor_bwd_point(s, W_ + w.gact, W_ + w.lin, W_ + w.out, n, w.Pout, omega0, scale0,
                               W_ + w.glin));
+  const LayerGemm g{wire_family_(WIRE_KIND_WIRE)};
   if (g_x) {
-    GemmEpiParams ep; ep.o0 = W_ + w.gxb; ep.ld0 = w.Pin;
-    LCHK(launch_gemm_nt(s, EPI_STORE, W_ + w.glin, w.Pout, W_ + w.btd, w.Pout, n, w.Pin, w.Pout, ep));
+    GemmEpiParams ep; ep.o0 = W_ + w.gxb; ep.ld0 = w.Pin; ep.ld1 = w.Pin;
+    LCHK(g.nt(s, EPI_STORE, W_ + w.glin, n, w.Pin, w.Pout, true, W_ + w.btf, W_ + w.btd, W_ + w.btf_x3,
+              W_ + w.btd_x3, ep));
     LCHK(launch_blocked_to_c64(s, W_ + w.gxb, n, in_features, w.Pin, (float*)g_x));
   }
-  LCHK(launch_gemm_tn(s, W_ + w.glin, w.Pout, W_ + w.xb, w.Pin, n, w.Pout, w.Pin, w.S, W_ + w.slab,
-                      W_ + w.bslab));
-  LCHK(launch_wgrad_reduce(s, NK_WIRE, W_ + w.slab, W_ + w.bslab, w.S, out_features, in_features,
-                           w.Pout, w.Pin, (float*)g_W, (float*)g_b, nullptr, nullptr));
+  LCHK(g.tn_reduce(s, NK_WIRE, W_ + w.glin, W_ + w.xb, n, w.Pout, w.Pin, out_features, in_features, W_ + w.slab,
+                   W_ + w.bslab, (float*)g_W, (float*)g_b, nullptr, nullptr));
   return WIRE_OK;
 }
 
@@ -185,13 +263,15 @@ static int real_epi_fwd(int kind) {
 static int real_forward_ws(hipStream_t s, const LayerWs& w, float* W_, int kind, const void* x, const void* Wt,
                            const void* b, float omega0, float scale0, int64_t n, int in, int out, int Pin,
                            int Pout) {
+  const LayerGemm g{wire_family_(kind)};
   LCHK(launch_pad_rows(s, (const float*)x, n, in, Pin, W_ + w.xb));
-  LCHK(launch_pack_hidden(s, kind, (const float*)Wt, (const float*)b, nullptr, nullptr, out, in, Pout, Pin,
-                          W_ + w.btf, W_ + w.btd, W_ + w.bias));
+  LCHK(g.pack(s, kind, (const float*)Wt, (const float*)b, nullptr, nullptr, out, in, Pout, Pin, W_ + w.btf,
+              W_ + w.btd, W_ + w.bias, W_ + w.btf_x3, W_ + w.btd_x3));
   GemmEpiParams ep;
   ep.bias = W_ + w.bias; ep.o0 = W_ + w.lin; ep.o1 = W_ + w.out; ep.ld0 = Pout; ep.ld1 = Pout;
   ep.omega = omega0; ep.scale = scale0; ep.kvalid = out;
-  LCHK(launch_gemm_nt(s, real_epi_fwd(kind), W_ + w.xb, Pin, W_ + w.btf, Pin, n, Pout, Pin, ep));
+  LCHK(g.nt(s, real_epi_fwd(kind), W_ + w.xb, n, Pout, Pin, false, W_ + w.btf, W_ + w.btd, W_ + w.btf_x3,
+            W_ + w.btd_x3, ep));
   return WIRE_OK;
 }
 
@@ -230,15 +310,15 @@ extern "C" int wire_real_layer_bwd(void* stream, int kind, const float* g_act, c
   LCHK(launch_pad_rows(s, g_act, n, out_features, Pout, W_ + w.gact));
   LCHK(launch_real_act_bwd_point(s, kind, W_ + w.gact, W_ + w.lin, W_ + w.out, n, Pout, omega0, scale0,
                                  W_ + w.glin));
+  const LayerGemm g{wire_family_(kind)};
   if (g_x) {
-    GemmEpiParams ep; ep.o0 = W_ + w.gxb; ep.ld0 = Pin;
-    LCHK(launch_gemm_nt(s, EPI_STORE, W_ + w.glin, Pout, W_ + w.btd, Pout, n, Pin, Pout, ep));
+    GemmEpiParams ep; ep.o0 = W_ + w.gxb; ep.ld0 = Pin; ep.ld1 = Pin;
+    LCHK(g.nt(s, EPI_STORE, W_ + w.glin, n, Pin, Pout, true, W_ + w.btf, W_ + w.btd, W_ + w.btf_x3, W_ + w.btd_x3,
+              ep));
     LCHK(launch_unpad_rows(s, W_ + w.gxb, n, in_features, Pin, g_x));
   }
-  const int S = gemm_tn_splits(n, Pout, Pin, w.S);
-  LCHK(launch_gemm_tn(s, W_ + w.glin, Pout, W_ + w.xb, Pin, n, Pout, Pin, S, W_ + w.slab, W_ + w.bslab));
-  LCHK(launch_wgrad_reduce(s, kind, W_ + w.slab, W_ + w.bslab, S, out_features, in_features, Pout, Pin, g_W,
-                           g_b, nullptr, nullptr));
+  LCHK(g.tn_reduce(s, kind, W_ + w.glin, W_ + w.xb, n, Pout, Pin, out_features, in_features, W_ + w.slab,
+                   W_ + w.bslab, g_W, g_b, nullptr, nullptr));
   return WIRE_OK;
 }
 
@@ -249,7 +329,7 @@ extern "C" int wire_real_layer_bwd(void* stream, int kind, const float* g_act, c
 namespace {
 struct Layer2dWs {
   int Pin, Pout, S, ldu;
-  int64_t xb, linsy, out, gact, glinsy, gxb, gup, btf, btd, bias, slab, bslab, crp, total;
+  int64_t xb, linsy, out, gact, glinsy, gxb, gup, btf, btd, bias, slab, bslab, crp, btf_x3, btd_x3, total;
 };
 Layer2dWs layer2d_ws(int64_t n, int in, int out) {
   Layer2dWs w{};
@@ -257,6 +337,7 @@ Layer2dWs layer2d_ws(int64_t n, int in, int out) {
   w.Pout = rup(2 * out, 64);
   w.ldu = w.Pout / 2;
   w.S = gemm_tn_splits(n, 2 * w.Pout, w.Pin, 64);
+  const int64_t s_max = std::max<int64_t>(w.S, layer_splits(FAM_X3, n, 2 * w.Pout, w.Pin));
   int64_t off = 0;
   auto take = [&](int64_t cnt) { int64_t o = off; off += rup64(cnt, 64); return o; };
   w.xb = take(n * w.Pin);
@@ -269,9 +350,11 @@ Layer2dWs layer2d_ws(int64_t n, int in, int out) {
   w.btf = take((int64_t)2 * w.Pout * w.Pin);
   w.btd = take((int64_t)2 * w.Pout * w.Pin);
   w.bias = take(2 * w.Pout);
-  w.slab = take((int64_t)w.S * 2 * w.Pout * w.Pin);
-  w.bslab = take((int64_t)w.S * 2 * w.Pout);
+  w.slab = take(s_max * 2 * w.Pout * w.Pin);
+  w.bslab = take(s_max * 2 * w.Pout);
   w.crp = take((int64_t)(colreduce_blocks(n) + 32) * w.ldu * 5);
+  w.btf_x3 = take(gemmx3_b_image_floats(2 * w.Pout, w.Pin));
+  w.btd_x3 = take(gemmx3_b_image_floats(w.Pin, 2 * w.Pout));
   w.total = off;
   return w;
 }
@@ -286,13 +369,15 @@ int layer2d_forward_ws(hipStream_t s, const Layer2dWs& w, float* W_, const void*
                           (const float*)Vt, (const float*)c, out, w.Pout, omega0, scale0, nullptr, W_ + w.out));
     return WIRE_OK;
   }
+  const LayerGemm g{wire_family_(WIRE_KIND_WIRE2D)};
   LCHK(launch_c64_to_blocked(s, (const float*)x, n, in, w.Pin, W_ + w.xb));
-  LCHK(launch_pack_hidden(s, NK_WIRE2D, (const float*)Wt, (const float*)b, (const float*)Vt, (const float*)c, out,
-                          in, w.Pout, w.Pin, W_ + w.btf, W_ + w.btd, W_ + w.bias));
+  LCHK(g.pack(s, NK_WIRE2D, (const float*)Wt, (const float*)b, (const float*)Vt, (const float*)c, out, in,
+              2 * w.Pout, w.Pin, W_ + w.btf, W_ + w.btd, W_ + w.bias, W_ + w.btf_x3, W_ + w.btd_x3));
   GemmEpiParams ep;
   ep.bias = W_ + w.bias; ep.o0 = W_ + w.linsy; ep.o1 = W_ + w.out; ep.ld0 = 2 * w.Pout; ep.ld1 = w.Pout;
   ep.omega = omega0; ep.scale = scale0; ep.kvalid = out;
-  LCHK(launch_gemm_nt(s, EPI_GABOR2D_FWD, W_ + w.xb, w.Pin, W_ + w.btf, w.Pin, n, 2 * w.Pout, w.Pin, ep));
+  LCHK(g.nt(s, EPI_GABOR2D_FWD, W_ + w.xb, n, 2 * w.Pout, w.Pin, false, W_ + w.btf, W_ + w.btd, W_ + w.btf_x3,
+            W_ + w.btd_x3, ep));
   return WIRE_OK;
 }
 }  // namespace
@@ -344,14 +429,14 @@ extern "C" int wire_gabor2d_bwd(void* stream, const void* g_act, const void* x, 
   }
   LCHK(launch_gabor2d_bwd_point(s, W_ + w.gact, W_ + w.linsy, W_ + w.out, n, w.Pout, omega0, scale0,
                                 W_ + w.glinsy));
+  const LayerGemm g{wire_family_(WIRE_KIND_WIRE2D)};
   if (g_x) {
-    GemmEpiParams ep; ep.o0 = W_ + w.gxb; ep.ld0 = w.Pin;
-    LCHK(launch_gemm_nt(s, EPI_STORE, W_ + w.glinsy, 2 * w.Pout, W_ + w.btd, 2 * w.Pout, n, w.Pin, 2 * w.Pout, ep));
+    GemmEpiParams ep; ep.o0 = W_ + w.gxb; ep.ld0 = w.Pin; ep.ld1 = w.Pin;
+    LCHK(g.nt(s, EPI_STORE, W_ + w.glinsy, n, w.Pin, 2 * w.Pout, true, W_ + w.btf, W_ + w.btd, W_ + w.btf_x3,
+              W_ + w.btd_x3, ep));
     LCHK(launch_blocked_to_c64(s, W_ + w.gxb, n, in_features, w.Pin, (float*)g_x));
   }
-  LCHK(launch_gemm_tn(s, W_ + w.glinsy, 2 * w.Pout, W_ + w.xb, w.Pin, n, 2 * w.Pout, w.Pin, w.S, W_ + w.slab,
-                      W_ + w.bslab));
-  LCHK(launch_wgrad_reduce(s, NK_WIRE2D, W_ + w.slab, W_ + w.bslab, w.S, out_features, in_features, 2 * w.Pout,
-                           w.Pin, (float*)g_W, (float*)g_b, (float*)g_V, (float*)g_c));
+  LCHK(g.tn_reduce(s, NK_WIRE2D, W_ + w.glinsy, W_ + w.xb, n, 2 * w.Pout, w.Pin, out_features, in_features,
+                   W_ + w.slab, W_ + w.bslab, (float*)g_W, (float*)g_b, (float*)g_V, (float*)g_c));
   return WIRE_OK;
 }

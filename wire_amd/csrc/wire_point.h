@@ -13,7 +13,7 @@ hipError_t launch_pack_final(hipStream_t s, int kind, const float* Wf, const flo
                              int P, int O, float* wf, float* bfr);
 
 // ---- first layer (D <= 4 inputs): elementwise, VALU/HBM-write bound
-// out [n][P] blocked; lin (optional): real nets [n][P]; wire2d [n][2*Kp] (u | p)
+// out [n][P] blocked; lin (optional): real nets [n][P]; wire: real u [n][P/2] (per-layer API)
 hipError_t launch_first_fwd(hipStream_t s, int kind, const float* coords, int64_t n, int D,
                             const float* W0, const float* b0, const float* V0, const float* c0,
                             int K, int P, float omega, float scale, float* lin, float* out);
@@ -88,6 +88,9 @@ hipError_t launch_posenc(hipStream_t s, const float* coords, int64_t n, int D, i
                          float* dst);
 
 // ---- training glue
+// idx_out[r] = pi_seed(first + r), r < count: a keyed bijection pi_seed of [0, n_total) (the epoch's shuffle)
+hipError_t launch_perm_indices(hipStream_t s, uint64_t seed, int64_t n_total, int64_t first, int64_t count,
+                               int64_t* idx_out);
 hipError_t launch_coords(hipStream_t s, const int64_t* idx, int64_t first, int64_t n,
                          const float* tx, int W, const float* ty, int H, const float* tz, int T,
                          float* coords);

@@ -144,6 +144,7 @@ __global__ void first_fwd_kernel(const float* __restrict__ coords, long long n, 
       gabor_fwd_real(u, omega, scale, o_re, o_im);
       out[row * P + c_re] = valid ? o_re : 0.f;
       out[row * P + c_re + 32] = valid ? o_im : 0.f;
+      if (lin) lin[row * nfeat + f] = valid ? u : 0.f;      // per-layer API only: real u, [n][P / 2]
     } else if (KIND == NK_WIRE2D) {
       float o_re, o_im;
       gabor2d_fwd(u, 0.f, p, 0.f, omega, scale, o_re, o_im);
@@ -1018,6 +1019,57 @@ hipError_t launch_posenc(hipStream_t s, const float* coords, int64_t n, int D, i
 // ===========================================================================
 // training glue
 // ===========================================================================
+// Keyed bijection of [0, n): the per-epoch shuffle of wire_image_denoise.py:142 / wire_occupancy.py:137
+// (torch.randperm) as a function of the POSITION, so that a rank generates exactly the slice of the epoch's
+// permutation it trains on -- O(shard) work and memory per rank whatever the world size and the grid size
+// (randperm sorts all n keys on every rank: 0.57 ms at n = 262 144, 1 GB of int64 at 512^3).
+// b = bits of the smallest power of two >= n; four rounds of  x = (x * M_r + K_r) mod 2^b; x ^= x >> s  (each
+// invertible mod 2^b), then cycle-walking: re-apply while x >= n (2^b < 2 n, so < 2 applications on average;
+// it terminates because the walk stays on the cycle of a permutation of [0, 2^b) that contains the start).
+// oracle/wire_oracle.py:hash_perm is the numpy twin (bit-exact integer arithmetic).
+__device__ __host__ inline unsigned long long perm_splitmix(unsigned long long z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+struct PermKeys { unsigned long long m[4], k[4]; };
+__device__ inline unsigned long long perm_apply(unsigned long long x, unsigned long long n, int b, int sh,
+                                                const PermKeys& K) {
+  const unsigned long long mask = (b >= 64) ? ~0ull : ((1ull << b) - 1ull);
+  do {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      x = (x * K.m[r] + K.k[r]) & mask;
+      x ^= x >> sh;
+    }
+  } while (x >= n);
+  return x;
+}
+__global__ void perm_indices_kernel(PermKeys K, long long n_total, int b, int sh, long long first, long long count,
+                                    int64_t* __restrict__ idx_out) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= count) return;
+  idx_out[r] = (int64_t)perm_apply((unsigned long long)(first + r), (unsigned long long)n_total, b, sh, K);
+}
+hipError_t launch_perm_indices(hipStream_t s, uint64_t seed, int64_t n_total, int64_t first, int64_t count,
+                               int64_t* idx_out) {
+  if (count <= 0) return hipSuccess;
+  if (n_total < 1 || first < 0 || first + count > n_total) return hipErrorInvalidValue;
+  int b = 0;
+  while (b < 63 && (1ull << b) < (unsigned long long)n_total) ++b;
+  if (b == 0) b = 1;                       // n = 1: domain {0, 1}, cycle-walking maps 0 -> 0
+  const int sh = b / 2 > 0 ? b / 2 : 1;
+  PermKeys K;
+  for (int r = 0; r < 4; ++r) {
+    K.m[r] = perm_splitmix(seed * 8 + r) | 1ull;          // odd multiplier: a bijection mod 2^b
+    K.k[r] = perm_splitmix(seed * 8 + 4 + r);
+  }
+  hipLaunchKernelGGL(perm_indices_kernel, dim3(cdiv(count, 256)), dim3(256), 0, s, K, (long long)n_total, b, sh,
+                     (long long)first, (long long)count, idx_out);
+  return hipGetLastError();
+}
+
 __global__ void coords_kernel(const int64_t* __restrict__ idx, long long first, long long n,
                               const float* __restrict__ tx, int W, const float* __restrict__ ty,
                               int H, const float* __restrict__ tz, int T,

@@ -108,6 +108,21 @@ class FusedTrainer:
         self.reducers = [FlatGradAllReducer(g, group, use_side_stream=side) for g in self.gbuf]
         self._cap = 0
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self._hidx: Optional[torch.Tensor] = None
+        if self.world > 1:
+            # replicas start from rank 0's parameters whatever seed each rank was built under; they stay
+            # identical because every rank applies the same Adam update to the same reduced gradient
+            self._broadcast_from_rank0(self.flat)
+
+    def _broadcast_from_rank0(self, t: torch.Tensor) -> None:
+        if dist.get_backend(self.group) == "gloo" and t.is_cuda:     # rehearsal backend: stage through the host
+            host = t.detach().cpu()
+            dist.broadcast(host, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                           group=self.group)
+            t.copy_(host)
+        else:
+            dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                           group=self.group)
 
     # ------------------------------------------------------------------ buffers
     def _reserve(self, n: int) -> None:
@@ -155,38 +170,67 @@ class FusedTrainer:
     # ------------------------------------------------------------------ one step
     def step(self, indices: Optional[torch.Tensor] = None, first: int = 0,
              count: Optional[int] = None) -> torch.Tensor:
-        """One optimizer step on a global batch: rows ``indices`` (int64 device
-        tensor of flat grid indices) or the range [first, first+count).
-        Returns the (device-resident, all-reduced) batch loss; no host sync."""
-        L, d = self.L, C.byref(self.desc)
-        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        """One optimizer step on a global batch: rows ``indices`` (contiguous int64 device
+        tensor of flat grid indices, every rank passes the same one) or the range
+        [first, first+count).  Returns the (device-resident, all-reduced) batch loss; no host sync."""
         if indices is not None:
-            if indices.dtype != torch.int64 or not indices.is_cuda:
-                raise ValueError("indices must be a CUDA int64 tensor")
+            if indices.dtype != torch.int64 or not indices.is_cuda or indices.dim() != 1:
+                raise ValueError("indices must be a 1-D CUDA int64 tensor")
+            if not indices.is_contiguous():
+                raise ValueError("indices must be contiguous (a strided view such as perm[::2] would be read "
+                                 "as its underlying storage); call .contiguous()")
             B = indices.numel()
         else:
             B = int(count if count is not None else self.npoints - first)
+            if first < 0 or first + B > self.npoints:
+                raise ValueError(f"rows [{first}, {first + B}) outside the grid of {self.npoints} points")
         lo, hi = shard_bounds(B, self.world, self.rank)
-        _lib.check(L.wire_pack_params(stream, d, self.param_ptrs, self.packed.data_ptr()), "pack")
+        idx_ptr = (indices.data_ptr() + 8 * lo) if indices is not None else None
+        return self._step_local(idx_ptr, first + lo, hi - lo, B)
+
+    def step_hashed(self, seed: int, first: int = 0, count: Optional[int] = None) -> torch.Tensor:
+        """One optimizer step on positions [first, first+count) of the epoch's shuffle ``pi_seed`` -- the
+        reference's ``indices = torch.randperm(H*W); b_indices = indices[b_idx:b_idx+maxpoints]``
+        (wire_image_denoise.py:142-146, wire_occupancy.py:137-142) with the permutation evaluated per position on
+        the device (wire_perm_indices): this rank generates only ITS shard of the batch, so the cost of the
+        shuffle does not grow with the world size or with the grid (512^3: no 1 GB index vector).  ``seed`` is
+        the epoch counter; every rank passes the same (seed, first, count).  No host sync."""
+        B = int(count if count is not None else self.npoints - first)
+        if first < 0 or first + B > self.npoints:
+            raise ValueError(f"positions [{first}, {first + B}) outside the epoch of {self.npoints} points")
+        lo, hi = shard_bounds(B, self.world, self.rank)
         nloc = hi - lo
+        if self._hidx is None or self._hidx.numel() < nloc:
+            self._hidx = torch.empty(max(nloc, 1), dtype=torch.int64, device=self.dev)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        _lib.check(self.L.wire_perm_indices(stream, int(seed) & 0xFFFFFFFFFFFFFFFF, self.npoints, first + lo, nloc,
+                                            self._hidx.data_ptr()), "perm_indices")
+        return self._step_local(self._hidx.data_ptr(), 0, nloc, B)
+
+    def _step_local(self, idx_ptr: Optional[int], first: int, nloc: int, B: int) -> torch.Tensor:
+        """This rank's shard of a global batch of B rows: ``nloc`` rows whose flat grid indices are the int64
+        device array at ``idx_ptr`` (or the range starting at ``first`` when None)."""
+        L, d = self.L, C.byref(self.desc)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        _lib.check(L.wire_pack_params(stream, d, self.param_ptrs, self.packed.data_ptr()), "pack")
         per = (nloc + self.micro - 1) // self.micro
         self._reserve(max(per, 1))
         tz_ptr = self.tz.data_ptr() if self.tz is not None else None
         Tn = self.grid[2] if self.tz is not None else 1
         for m in range(self.micro):
-            mlo = lo + m * per
-            n = max(0, min(hi, mlo + per) - mlo)
+            mlo = m * per
+            n = max(0, min(nloc, mlo + per) - mlo)
             g = self.gbuf[m]
             if n == 0:
                 g.zero_()
             else:
-                idx_ptr = (indices.data_ptr() + 8 * mlo) if indices is not None else None
-                _lib.check(L.wire_coords_from_index(stream, idx_ptr, first + mlo, n, self.tx.data_ptr(),
+                ip = (idx_ptr + 8 * mlo) if idx_ptr is not None else None
+                _lib.check(L.wire_coords_from_index(stream, ip, first + mlo, n, self.tx.data_ptr(),
                                                     self.grid[1], self.ty.data_ptr(), self.grid[0],
                                                     tz_ptr, Tn, self.coords.data_ptr()), "coords")
                 _lib.check(L.wire_train_fwd_bwd(
                     stream, d, self.packed.data_ptr(), self.coords.data_ptr(), n, self.target.data_ptr(),
-                    idx_ptr, first + mlo, n / float(B), self.y.data_ptr(), self.gy.data_ptr(),
+                    ip, first + mlo, n / float(B), self.y.data_ptr(), self.gy.data_ptr(),
                     g.data_ptr() + 4 * self.count,
                     self.rec.data_ptr() if self.rec is not None else None, self.partial.data_ptr(),
                     self.act.data_ptr(), self.act_bytes, self.scratch.data_ptr(), self.scr_bytes,
