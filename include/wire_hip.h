@@ -177,8 +177,8 @@ int wire_coords_from_index(void* stream, const int64_t* idx, int64_t first,
 /* The per-epoch shuffle (torch.randperm(H*W) at wire_image_denoise.py:142, wire_occupancy.py:137) as a keyed
  * bijection pi_seed of [0, n_total) evaluated per position: idx_out[r] = pi_seed(first + r), r < count.  A rank
  * of a data-parallel job generates only the slice of the epoch's permutation it trains on (cost O(count),
- * independent of n_total and of the world size).  Integer arithmetic, bit-exact with oracle/wire_oracle.py:
- * hash_perm; NOT the sequence torch.randperm draws.                                                  */
+ * independent of n_total and of the world size).  Integer arithmetic (a numpy twin in the
+ * test suite reproduces it bit for bit); NOT the sequence torch.randperm draws.                                                  */
 int wire_perm_indices(void* stream, uint64_t seed, int64_t n_total, int64_t first, int64_t count,
                       int64_t* idx_out);
 /* loss = mean((y - target[idx])^2) over n*O elements scaled by `weight`

@@ -1026,7 +1026,7 @@ hipError_t launch_posenc(hipStream_t s, const float* coords, int64_t n, int D, i
 // b = bits of the smallest power of two >= n; four rounds of  x = (x * M_r + K_r) mod 2^b; x ^= x >> s  (each
 // invertible mod 2^b), then cycle-walking: re-apply while x >= n (2^b < 2 n, so < 2 applications on average;
 // it terminates because the walk stays on the cycle of a permutation of [0, 2^b) that contains the start).
-// oracle/wire_oracle.py:hash_perm is the numpy twin (bit-exact integer arithmetic).
+// (tests/test_shuffle.py holds the bit-exact numpy twin.)
 __device__ __host__ inline unsigned long long perm_splitmix(unsigned long long z) {
   z += 0x9e3779b97f4a7c15ull;
   z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
