@@ -283,7 +283,8 @@ int gemmx3g_mode() { return g_x3_glds; }
 // true when this file has a kernel for the call (large batches of the Gabor / store epilogues)
 bool gemmx3g_handles(int epi, int64_t M) {
   if (!g_x3_glds || M < 4096) return false;
-  return epi == EPI_STORE || epi == EPI_GABOR_FWD || epi == EPI_GABOR_BWD || epi == EPI_GABOR_BWD_FIRST;
+  if (epi == EPI_STORE || epi == EPI_GABOR_FWD || epi == EPI_GABOR_BWD || epi == EPI_GABOR_BWD_FIRST) return true;
+  return g_x3_glds == 1 && epi >= EPI_SIREN_FWD && epi <= EPI_GABOR2D_BWD_FIRST;
 }
 
 hipError_t launch_gemmx3g_nt(hipStream_t s, int epi, const float* A, int lda, const void* Bx3, int64_t M, int Nc,
@@ -303,7 +304,22 @@ hipError_t launch_gemmx3g_nt(hipStream_t s, int epi, const float* A, int lda, co
     X3G_CASE(EPI_GABOR_FWD)
     X3G_CASE(EPI_GABOR_BWD)
     X3G_CASE(EPI_GABOR_BWD_FIRST)
-    default: return hipErrorInvalidValue;
+    default: break;
   }
 #undef X3G_CASE
+  // the other net kinds: 256 x 128 tile only
+  switch (epi) {
+    case EPI_SIREN_FWD: return launchx3g_t<EPI_SIREN_FWD, 2, 4, 4, 1, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_GAUSS_FWD: return launchx3g_t<EPI_GAUSS_FWD, 2, 4, 4, 1, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_RELU_FWD: return launchx3g_t<EPI_RELU_FWD, 2, 4, 4, 1, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_SIREN_BWD: return launchx3g_t<EPI_SIREN_BWD, 2, 4, 4, 1, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_GAUSS_BWD: return launchx3g_t<EPI_GAUSS_BWD, 2, 4, 4, 1, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_RELU_BWD: return launchx3g_t<EPI_RELU_BWD, 2, 4, 4, 1, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_GABOR2D_FWD:
+      if (Nc & 127) return hipErrorInvalidValue;
+      return launchx3g_t<EPI_GABOR2D_FWD, 2, 4, 4, 1, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_GABOR2D_BWD: return launchx3g_t<EPI_GABOR2D_BWD, 2, 4, 4, 1, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    case EPI_GABOR2D_BWD_FIRST: return launchx3g_t<EPI_GABOR2D_BWD_FIRST, 2, 4, 4, 1, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+    default: return hipErrorInvalidValue;
+  }
 }
