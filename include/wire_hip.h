@@ -143,6 +143,12 @@ int wire_gabor_bwd(void* stream, const void* g_act, const void* x,
                    const void* W, const void* b, float omega0, float scale0,
                    int64_t n, int in_features, int out_features, int is_first,
                    void* g_x, void* g_W, void* g_b, void* ws, int64_t ws_bytes);
+/* gradient of a TRAINABLE omega_0 / scale_0 (ComplexGaborLayer(..., trainable=True), modules/wire.py:80-81):
+ * out2 (device, 2 floats) = { dL/d omega_0, dL/d scale_0 } for the upstream gradient g_act; same operands and
+ * workspace as wire_gabor_bwd.                                                                       */
+int wire_gabor_hparam_grad(void* stream, const void* g_act, const void* x, const void* W, const void* b,
+                           float omega0, float scale0, int64_t n, int in_features, int out_features,
+                           int is_first, float* out2, void* ws, int64_t ws_bytes);
 /* final nn.Linear(K,O,cfloat) + .real (modules/wire.py:156-157,164-165)    */
 int wire_final_fwd(void* stream, const void* z, const void* Wf, const void* bf,
                    int64_t n, int in_features, int out_features, float* y,
@@ -216,6 +222,15 @@ int wire_adam_step_flat(void* stream, float* param, const float* grad,
 int wire_eval_metric(void* stream, int mode, const float* rec, const float* gt,
                      int64_t count, float thres, float* out2, float* partial);
 
+/* Best-reconstruction tracking of the drivers without a device->host copy per epoch
+ * (wire_image_denoise.py:176-178: `if (mse_array[epoch] < best_mse) or (epoch == 0): best_mse = ...; best_img = imrec`;
+ * wire_occupancy.py:170-172 with lossval): if force != 0 or metric[0] < best_metric[0], copy src[0..count) to dst
+ * and metric[0] to best_metric[0]; updated (optional, device int) receives 1 / 0.  All pointers device.      */
+int wire_track_best(void* stream, const float* metric, float* best_metric, int force, const float* src,
+                    float* dst, int64_t count, int* updated);
+/* torch.sigmoid of the dense occupancy query before the cube is written (modules/volutils.py:128-131)       */
+int wire_sigmoid_inplace(void* stream, float* x, int64_t count);
+
 /* ---- ComplexGaborLayer2D (modules/wire2d.py:21-67) on native tensors ---------------------
  * act = exp(j w0 lin) exp(-s0^2 (|lin|^2 + |sy|^2)),  lin = x W^T + b,  sy = x V^T + c (scale_orth).
  * Same conventions as wire_gabor_fwd / wire_gabor_bwd: x, act, g_act, g_x complex64 [n][features]
@@ -245,10 +260,12 @@ int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* 
  *     MAC); 0 = 4-multiplication real-expanded GEMMs.
  * "x3_tall" (default 1), "x3_tn_tall" (default 0): 256-row tiles in the split-bf16
  *     NT / TN kernels.   "nt_bk" (16 | 32): K-slab depth of the fp32 4M NT kernel.
- * Buffer sizes (wire_packed_floats, wire_act_bytes, wire_bwd_scratch_bytes) do not
- * depend on the knobs; the CONTENT of a packed buffer does: re-run
- * wire_pack_params after changing one, and do not change one between a forward
- * and its backward.                                                            */
+ * "x3_glds" (default 0): 1 / 2 = LDS-DMA editions of the split-bf16 NT GEMM at M >= 4096
+ *     (wire_gemmx3g.hip; bit-identical results).
+ * Neither buffer sizes (wire_packed_floats, wire_act_bytes, wire_bwd_scratch_bytes) nor
+ * buffer CONTENTS depend on the knobs: wire_pack_params writes the weight image of every
+ * family, activations are fp32 blocked rows for all of them, so a knob may change between
+ * a forward and its backward.                                                  */
 int wire_tune_set(const char* key, int value);
 int wire_tune_get(const char* key);   /* "split_bf16" | "complex_3m" -> value; < 0 = error */
 

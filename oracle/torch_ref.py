@@ -132,3 +132,38 @@ def train_steps(p: TParams, coords: torch.Tensor, target: torch.Tensor,
         sched.step()
         losses.append(float(loss.detach()))
     return losses, {k: v.detach() for k, v in params.items()}
+
+
+def driver_loop(p: TParams, coords: torch.Tensor, gt: torch.Tensor, hidden_layers: int, first_omega0: float,
+                hidden_omega0: float, scale0: float, lr: float, niters: int, maxpoints: int, gamma: float,
+                perms, squeeze_occupancy: bool = False):
+    """The reference drivers' training loop on CPU (wire_image_denoise.py:141-178 / wire_occupancy.py:136-172):
+    per epoch ``indices = perms[epoch]`` (the driver's ``torch.randperm``), minibatches of ``maxpoints`` rows,
+    ``rec[b_indices] = pixelvalues``, MSE, zero_grad / backward / Adam.step, LambdaLR(gamma ** min(x / niters, 1))
+    stepped per epoch, best-so-far bookkeeping on the epoch's reconstruction error (image driver) or on the last
+    minibatch loss (occupancy driver).  coords [N, D], gt [N, O].  Returns (per-step losses, rec, best_img,
+    params-after)."""
+    params = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    opt = torch.optim.Adam(lr=lr, params=list(params.values()))
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda x: gamma ** min(x / niters, 1))
+    N = coords.shape[0]
+    rec = torch.zeros_like(gt)
+    losses, best, best_img = [], float("inf"), None
+    for epoch in range(niters):
+        indices = perms[epoch]
+        for b in range(0, N, maxpoints):
+            bi = indices[b:min(N, b + maxpoints)]
+            y = wire_forward(params, coords[bi][None], hidden_layers, first_omega0, hidden_omega0, scale0)[0]
+            with torch.no_grad():
+                rec[bi] = y
+            loss = ((y - gt[bi]) ** 2).mean()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        sched.step()
+        with torch.no_grad():
+            metric = losses[-1] if squeeze_occupancy else float(((gt - rec) ** 2).mean())
+        if metric < best or (epoch == 0 and not squeeze_occupancy):
+            best, best_img = metric, rec.clone()
+    return losses, rec, best_img, {k: v.detach() for k, v in params.items()}

@@ -216,7 +216,96 @@ def misc():
     print("misc: nparams_2x300 =", rec["nparams_2x300"], "psnr =", rec["psnr_val"])
 
 
+def misc2():
+    """Round-2 known answers: volutils.get_IoU (numpy path; mcubes / open3d / skimage are absent and only needed by
+    the mesh helpers, so empty stubs are registered as for cv2), ComplexGaborLayer(trainable=True) gradients,
+    outermost_linear=False nets, a wire net without hidden layers."""
+    for name in ("mcubes", "open3d", "skimage", "skimage.metrics"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["skimage.metrics"].structural_similarity = None
+    from modules import volutils
+    rec = {}
+    rng = np.random.default_rng(11)
+    # ---- IoU (modules/volutils.py:74-91): preds binarised IN PLACE at thres, then |and| / |or|
+    pred = rng.random(5000).astype(np.float32)
+    gt = (rng.random(5000) > 0.6).astype(np.float32)
+    work = pred.copy()
+    rec["iou_pred"], rec["iou_gt"], rec["iou_thres"] = pred, gt, np.float32(0.5)
+    rec["iou_val"] = np.float64(volutils.get_IoU(work, gt, 0.5))
+    rec["iou_pred_after"] = work                               # the in-place binarisation the caller observes
+    rec["iou_val_nothres"] = np.float64(volutils.get_IoU((pred > 0.7).astype(np.float32), gt, None))
+    rec["iou_batch_val"] = np.float64(volutils.get_IoU_batch(torch.tensor(pred.copy()), torch.tensor(gt), 0.5, 1024)) \
+        if False else np.float64(-1)                            # torch path calls .cuda(): not runnable here
+    # ---- ComplexGaborLayer(trainable=True): gradients of omega_0 / scale_0 (modules/wire.py:80-81)
+    for tag, is_first, fin in (("hid", False, 24), ("first", True, 3)):
+        torch.manual_seed(21)
+        layer = wire.ComplexGaborLayer(fin, 40, is_first=is_first, omega0=9.0, sigma0=4.0, trainable=True)
+        n = 300
+        if is_first:
+            x = torch.tensor(rng.uniform(-1, 1, (n, fin)).astype(np.float32))
+        else:
+            x = torch.tensor((0.4 * (rng.standard_normal((n, fin)) + 1j * rng.standard_normal((n, fin)))).astype(np.complex64))
+        g = torch.tensor((rng.standard_normal((n, 40)) + 1j * rng.standard_normal((n, 40))).astype(np.complex64))
+        for dbl in (False, True):
+            lay = wire.ComplexGaborLayer(fin, 40, is_first=is_first, omega0=9.0, sigma0=4.0, trainable=True)
+            lay.load_state_dict(layer.state_dict())
+            xx = x.clone()
+            gg = g.clone()
+            if dbl:
+                to_double(lay)
+                xx = xx.to(torch.double if is_first else torch.cdouble)
+                gg = gg.to(torch.cdouble)
+            xx.requires_grad_(not is_first)
+            out = lay(xx)
+            (out.real * gg.real + out.imag * gg.imag).sum().backward()
+            sfx = "64" if dbl else ""
+            rec[f"tr_{tag}_out{sfx}"] = out.detach().numpy()
+            rec[f"tr_{tag}_g_omega{sfx}"] = lay.omega_0.grad.numpy()
+            rec[f"tr_{tag}_g_scale{sfx}"] = lay.scale_0.grad.numpy()
+            rec[f"tr_{tag}_g_W{sfx}"] = lay.linear.weight.grad.numpy()
+            rec[f"tr_{tag}_g_b{sfx}"] = lay.linear.bias.grad.numpy()
+            if not is_first:
+                rec[f"tr_{tag}_g_x{sfx}"] = xx.grad.numpy()
+        rec[f"tr_{tag}_x"], rec[f"tr_{tag}_g"] = x.numpy(), g.numpy()
+        for k, v in layer.state_dict().items():
+            rec[f"tr_{tag}_p:{k}"] = v.numpy()
+    # ---- outermost_linear=False (modules/siren.py:81-84, gauss.py:63-66, relu.py:116-119) and wire with L = 0
+    coords = torch.tensor(rng.uniform(-1, 1, (1, 200, 2)).astype(np.float32))
+    target = torch.tensor(rng.uniform(0, 1, (1, 200, 3)).astype(np.float32))
+    rec["ol_coords"], rec["ol_target"] = coords.numpy(), target.numpy()
+    cases = [("siren", lambda: siren.INR(2, 48, 2, 3, False, 30.0, 30.0, 10.0)),
+             ("gauss", lambda: gauss.INR(2, 48, 2, 3, False, 30.0, 30.0, 10.0)),
+             ("relu", lambda: relu.INR(2, 48, 2, 3, False, 30.0, 30.0, 10.0)),
+             ("wireL0", lambda: wire.INR(2, 64, 0, 0, 3, True, 7.0, 7.0, 6.0))]
+    for tag, mk in cases:
+        torch.manual_seed(31)
+        model = mk()
+        for k, v in model.state_dict().items():
+            rec[f"ol_{tag}_p:{k}"] = v.numpy().copy()
+        for dbl in (False, True):
+            m2 = mk()
+            m2.load_state_dict(model.state_dict())
+            c, t = coords, target
+            if dbl:
+                to_double(m2)
+                c, t = coords.double(), target.double()
+            y = m2(c)
+            loss = ((y - t) ** 2).mean()
+            loss.backward()
+            sfx = "64" if dbl else ""
+            rec[f"ol_{tag}_y{sfx}"] = y.detach().numpy()
+            for k, prm in m2.named_parameters():
+                if prm.grad is not None:
+                    rec[f"ol_{tag}_g{sfx}:{k}"] = prm.grad.numpy()
+    rec["meta_torch"] = np.array(torch.__version__)
+    np.savez_compressed(os.path.join(OUT, "misc2.npz"), **rec)
+    print("misc2: iou =", rec["iou_val"], "trainable g_omega (hid) =", rec["tr_hid_g_omega"], rec["tr_hid_g_omega64"])
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "misc2":
+        misc2()
+        sys.exit(0)
     N = 512
     # ---- small, everything stored
     run_case("small_wire_d2", "wire", 2, 64, 2, 3, 7.0, 7.0, 6.0, N, 0, False)
@@ -244,3 +333,4 @@ if __name__ == "__main__":
     run_case("full_cfg5_posenc_4x256", "relu", 2, 256, 4, 3, 30.0, 30.0, 10.0, NF, 0, True,
              pos_encode=True, sidelength=512)
     misc()
+    misc2()

@@ -157,3 +157,36 @@ def test_avgpool_loss_restatement_matches_torch(H, W, scale):
     assert abs(loss - float(lt.detach())) <= 1e-14 * max(1.0, abs(float(lt.detach())))
     np.testing.assert_allclose(g, yt.grad.numpy(), rtol=0, atol=1e-15)
     np.testing.assert_allclose(rec, pooled.reshape(O, -1).T.detach().numpy(), rtol=0, atol=1e-14)
+
+
+def test_iou_pinned_by_reference_known_answer():
+    """oracle.iou == modules/volutils.get_IoU on the reference-generated vector (tests/golden/misc2.npz), and the
+    reference's in-place binarisation of ``preds`` is what the fixture recorded."""
+    m2 = load_golden("misc2")
+    val = wo.iou(m2["iou_pred"], m2["iou_gt"], float(m2["iou_thres"]))
+    assert abs(val - float(m2["iou_val"])) < 1e-12
+    after = np.where(m2["iou_pred"] < m2["iou_thres"], 0.0, 1.0).astype(np.float32)
+    np.testing.assert_array_equal(after, m2["iou_pred_after"])
+    assert abs(wo.iou((m2["iou_pred"] > 0.7).astype(np.float32), m2["iou_gt"], None) - float(m2["iou_val_nothres"])) < 1e-12
+
+
+def test_trainable_gabor_gradients_closed_form():
+    """d out / d omega_0 = j lin out, d out / d scale_0 = -2 s0 |lin|^2 out (ComplexGaborLayer(trainable=True),
+    modules/wire.py:80-81) against the reference's autograd (fp64 fixture)."""
+    m2 = load_golden("misc2")
+    for tag in ("hid", "first"):
+        W = m2[f"tr_{tag}_p:linear.weight"]
+        b = m2[f"tr_{tag}_p:linear.bias"]
+        x, g = m2[f"tr_{tag}_x"], m2[f"tr_{tag}_g"].astype(np.complex128)
+        lin = x.astype(np.complex128 if np.iscomplexobj(W) else np.float64) @ W.astype(lin_dtype(W)).T + b
+        out = wo.gabor_act(lin, 9.0, 4.0)
+        assert relmax(out, m2[f"tr_{tag}_out64"]) < 1e-12
+        c = np.conj(out) * g
+        g_om = np.sum(lin.real * c.imag - lin.imag * c.real)
+        g_sc = -2.0 * 4.0 * np.sum(np.abs(lin) ** 2 * c.real)
+        assert abs(g_om - float(m2[f"tr_{tag}_g_omega64"][0])) <= 1e-10 * abs(g_om)
+        assert abs(g_sc - float(m2[f"tr_{tag}_g_scale64"][0])) <= 1e-10 * abs(g_sc)
+
+
+def lin_dtype(W):
+    return np.complex128 if np.iscomplexobj(W) else np.float64

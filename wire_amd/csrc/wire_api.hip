@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -48,15 +49,16 @@ extern "C" const char* wire_last_error(void) { return g_err.c_str(); }
 namespace {
 struct ProfRec { hipEvent_t a, b; int cls; double flops; };
 std::mutex g_prof_mu;
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
 std::vector<ProfRec> g_prof_recs;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 
 struct ProfScope {
   hipStream_t s; int cls; double flops; bool on; hipEvent_t a{}, b{};
   ProfScope(hipStream_t s_, int cls_, double flops_) : s(s_), cls(cls_), flops(flops_), on(false) {
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;   // profiling off: no lock on the launch path
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (!g_prof_on) return;
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
     on = true;
     if (!g_prof_pool.empty()) {
       a = g_prof_pool.back().first; b = g_prof_pool.back().second; g_prof_pool.pop_back();
@@ -76,7 +78,7 @@ struct ProfScope {
 
 extern "C" int wire_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof_on = on != 0;
+  g_prof_on.store(on != 0);
   return WIRE_OK;
 }
 extern "C" int wire_prof_read(double* ms_total, int64_t* launches, double* flops_total) {
@@ -135,7 +137,7 @@ struct Plan {
   bool cplx, first_gemm, m3, x3;
   int P, Pl, Din, Pin0, ldu, ntens, per_layer, Kp;
   // packed image offsets (floats); index l = 0..L (l = 0 only when first_gemm)
-  std::vector<int64_t> off_fwd, off_dg, off_bias, off_fwd_x3, off_dg_x3;
+  std::vector<int64_t> off_fwd, off_dg, off_bias, off_fwd_x3, off_dg_x3, off_fwd_3m, off_dg_3m;
   int64_t off_wf, off_bf, off_first, total_packed;
   std::vector<int64_t> tfloats;
 };
@@ -179,16 +181,22 @@ int make_plan(const wire_net_desc* d, Plan& p) {
   int64_t off = 0;
   p.off_fwd.assign(p.L + 1, -1); p.off_dg.assign(p.L + 1, -1); p.off_bias.assign(p.L + 1, -1);
   p.off_fwd_x3.assign(p.L + 1, -1); p.off_dg_x3.assign(p.L + 1, -1);
+  p.off_fwd_3m.assign(p.L + 1, -1); p.off_dg_3m.assign(p.L + 1, -1);
   for (int l = p.first_gemm ? 0 : 1; l <= p.L; ++l) {
     const int64_t pin = (l == 0) ? p.Pin0 : p.P;
-    // sized for the largest user (the real-expanded fp32 image; the 3M planes need half of it) and with the
-    // split-bf16 images always reserved, so that a packed buffer stays valid when the tuning flags change
+    // every family's image is ALWAYS written by wire_pack_params (real-expanded fp32, its split-bf16 form and,
+    // for `wire`, the blocked complex planes of the 3M kernels), so a packed buffer stays valid whatever the
+    // tuning flags are when it is used (e.g. changed between a forward and its backward)
     const int64_t img = (int64_t)p.Pl * pin;
     p.off_fwd[l] = off; off += img;
     p.off_dg[l] = off; off += img;
     p.off_bias[l] = off; off += p.Pl;
     p.off_fwd_x3[l] = off; off += gemmx3_b_image_floats(p.Pl, (int)pin);
     p.off_dg_x3[l] = off; off += gemmx3_b_image_floats((int)pin, p.Pl);
+    if (p.kind == WIRE_KIND_WIRE && l >= 1) {
+      p.off_fwd_3m[l] = off; off += (int64_t)p.Kp * p.P;
+      p.off_dg_3m[l] = off; off += (int64_t)p.Kp * p.P;
+    }
   }
   p.off_wf = off; off += (int64_t)p.O * p.P;
   p.off_bf = off; off += 64;
@@ -329,16 +337,13 @@ extern "C" int wire_pack_params(void* stream, const wire_net_desc* d, const void
     const float* c = p.per_layer == 4 ? (const float*)params[p.per_layer * l + 3] : nullptr;
     const int kin = (l == 0) ? p.Din : p.K;
     const int pin = (l == 0) ? p.Pin0 : p.P;
-    if (p.m3)
-      HIPCHK(launch_pack3m(s, W, b, p.K, p.K, p.Kp, p.Kp, packed + p.off_fwd[l], packed + p.off_dg[l],
+    HIPCHK(launch_pack_hidden(s, p.kind, W, b, V, c, p.K, kin, p.P, pin, packed + p.off_fwd[l],
+                              packed + p.off_dg[l], packed + p.off_bias[l]));
+    HIPCHK(launch_x3_split_b(s, packed + p.off_fwd[l], pin, p.Pl, pin, packed + p.off_fwd_x3[l]));
+    HIPCHK(launch_x3_split_b(s, packed + p.off_dg[l], p.Pl, pin, p.Pl, packed + p.off_dg_x3[l]));
+    if (p.off_fwd_3m[l] >= 0)     // same bias image (blocked planar) as launch_pack_hidden wrote
+      HIPCHK(launch_pack3m(s, W, b, p.K, p.K, p.Kp, p.Kp, packed + p.off_fwd_3m[l], packed + p.off_dg_3m[l],
                            packed + p.off_bias[l]));
-    else
-      HIPCHK(launch_pack_hidden(s, p.kind, W, b, V, c, p.K, kin, p.P, pin, packed + p.off_fwd[l],
-                                packed + p.off_dg[l], packed + p.off_bias[l]));
-    if (p.x3) {
-      HIPCHK(launch_x3_split_b(s, packed + p.off_fwd[l], pin, p.Pl, pin, packed + p.off_fwd_x3[l]));
-      HIPCHK(launch_x3_split_b(s, packed + p.off_dg[l], p.Pl, pin, p.Pl, packed + p.off_dg_x3[l]));
-    }
   }
   HIPCHK(launch_pack_final(s, p.kind, (const float*)params[p.ntens - 2],
                            (const float*)params[p.ntens - 1], p.K, p.P, p.O, packed + p.off_wf,
@@ -397,7 +402,7 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
     ep.ld0 = p.Pl; ep.ld1 = p.P; ep.omega = p.w; ep.scale = p.s; ep.kvalid = p.K;
     ProfScope ps(s, 0, 2.0 * n * p.Pl * p.P);
     if (p.m3)
-      HIPCHK(launch_gemm3m_nt(s, EPI_GABOR_FWD, out_l(l - 1), p.P, packed + p.off_fwd[l], p.P, n, p.Kp,
+      HIPCHK(launch_gemm3m_nt(s, EPI_GABOR_FWD, out_l(l - 1), p.P, packed + p.off_fwd_3m[l], p.P, n, p.Kp,
                               p.Kp, ep));
     else if (p.x3)
       HIPCHK(launch_gemmx3_nt(s, epi_fwd(p.kind), out_l(l - 1), p.P, packed + p.off_fwd_x3[l], n, p.Pl,
@@ -464,7 +469,20 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
     HIPCHK(launch_final_reduce(s, p.kind, Sx + sc.fpw, Sx + sc.fpb, nbf, p.O, p.K, p.P,
                                (float*)grads[p.ntens - 2], (float*)grads[p.ntens - 1]));
   }
-  if (p.L == 0 && p.cplx) return fail(WIRE_ERR_ARG, "hidden_layers = 0 is not supported for complex nets");
+  if (p.L == 0 && p.cplx) {
+    // no hidden layer (net = first Gabor layer + final linear): gcur holds the raw g_out0; the first layer's
+    // activation gradient is an elementwise pass (u recomputed from the coordinates), then the column sums below
+    ProfScope ps(s, 3, 0);
+    const float* W0 = packed + first_native_off(p, 0);
+    const float* b0 = packed + first_native_off(p, 1);
+    if (p.kind == WIRE_KIND_WIRE)
+      HIPCHK(launch_gabor_bwd_first_point(s, gcur, out_l(0), coords, p.D, W0, b0, n, p.K, p.P, p.w1, p.s,
+                                          Sx + sc.gu, p.ldu));
+    else
+      HIPCHK(launch_gabor2d_bwd_first_point(s, gcur, out_l(0), coords, p.D, W0, b0, packed + first_native_off(p, 2),
+                                            packed + first_native_off(p, 3), n, p.K, p.P, p.w1, p.s, Sx + sc.gu,
+                                            p.ldu));
+  }
 
   // ---- hidden layers L..1
   for (int l = p.L; l >= 1; --l) {
@@ -509,7 +527,7 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
     if (!p.cplx && l == 1) ep.ld0 = p.P;
     { ProfScope ps(s, 1, 2.0 * n * p.Pl * p.P);
       if (p.m3)
-        HIPCHK(launch_gemm3m_nt(s, epi, gcur, p.P, packed + p.off_dg[l], p.P, n, p.Kp, p.Kp, ep));
+        HIPCHK(launch_gemm3m_nt(s, epi, gcur, p.P, packed + p.off_dg_3m[l], p.P, n, p.Kp, p.Kp, ep));
       else if (p.x3)
         HIPCHK(launch_gemmx3_nt(s, epi, gcur, p.Pl, packed + p.off_dg_x3[l], n, p.P, p.Pl, ep));
       else
@@ -570,7 +588,7 @@ extern "C" int wire_train_fwd_bwd(void* stream, const wire_net_desc* d, const fl
   if (n <= 0) return fail(WIRE_ERR_ARG, "wire_train_fwd_bwd needs n > 0");
   if (!target || !y || !g_y || !loss_out || !partial) return fail(WIRE_ERR_ARG, "null pointer");
   hipStream_t s = (hipStream_t)stream;
-  const bool fuse = (p.kind == WIRE_KIND_WIRE) && p.L >= 1 && p.O <= 4 && final_fused_supported(p.P);
+  const bool fuse = (p.kind == WIRE_KIND_WIRE) && p.L >= 1 && p.O <= 4 && final_fused_supported(p.P, p.O);
   if (!fuse) {
     if (int rc = mlp_fwd_core(stream, p, packed, coords, n, y, act, act_bytes, 1, true)) return rc;
     { ProfScope ps(s, 3, 0);
@@ -652,6 +670,21 @@ extern "C" int wire_eval_metric(void* stream, int mode, const float* rec, const 
     return fail(WIRE_ERR_ARG, "bad argument to wire_eval_metric");
   ProfScope ps((hipStream_t)stream, 3, 0);
   HIPCHK(launch_metric((hipStream_t)stream, mode, rec, gt, count, thres, out2, partial));
+  return WIRE_OK;
+}
+
+extern "C" int wire_track_best(void* stream, const float* metric, float* best_metric, int force, const float* src,
+                               float* dst, int64_t count, int* updated) {
+  if (!metric || !best_metric || count < 0 || (count > 0 && (!src || !dst)))
+    return fail(WIRE_ERR_ARG, "bad argument to wire_track_best");
+  if (count > 0 && (((uintptr_t)src | (uintptr_t)dst) & 15)) return fail(WIRE_ERR_ARG, "src / dst must be 16-byte aligned");
+  ProfScope ps((hipStream_t)stream, 3, 0);
+  HIPCHK(launch_track_best((hipStream_t)stream, metric, best_metric, force, src, dst, count, updated));
+  return WIRE_OK;
+}
+extern "C" int wire_sigmoid_inplace(void* stream, float* x, int64_t count) {
+  if (count < 0 || (count > 0 && !x)) return fail(WIRE_ERR_ARG, "bad argument to wire_sigmoid_inplace");
+  HIPCHK(launch_sigmoid((hipStream_t)stream, x, count));
   return WIRE_OK;
 }
 

@@ -214,6 +214,26 @@ extern "C" int wire_gabor_bwd(void* stream, const void* g_act, const void* x, co
   return WIRE_OK;
 }
 
+// trainable omega_0 / scale_0 (ComplexGaborLayer(trainable=True), modules/wire.py:80-81): out2 = {dL/d omega_0,
+// dL/d scale_0} (device).  Recomputes the layer's forward from x, like wire_gabor_bwd.
+extern "C" int wire_gabor_hparam_grad(void* stream, const void* g_act, const void* x, const void* W, const void* b,
+                                      float omega0, float scale0, int64_t n, int in_features, int out_features,
+                                      int is_first, float* out2, void* ws, int64_t ws_bytes) {
+  if (n <= 0 || in_features < 1 || out_features < 1 || !g_act || !x || !W || !b || !out2 || !ws)
+    return wire_fail_(WIRE_ERR_ARG, "bad argument to wire_gabor_hparam_grad");
+  const LayerWs w = layer_ws(n, in_features, out_features);
+  if (ws_bytes < w.total * 4) return wire_fail_(WIRE_ERR_SIZE, "layer workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* W_ = (float*)ws;
+  if (int rc = layer_forward_ws(s, w, W_, x, W, b, omega0, scale0, n, in_features, out_features, is_first, true))
+    return rc;
+  LCHK(launch_c64_to_blocked(s, (const float*)g_act, n, out_features, w.Pout, W_ + w.gact));
+  // partial sums live in the (unused here) g_lin region: 2 * ceil(n / 32) floats <= n * Pout
+  LCHK(launch_gabor_hparam_grad(s, W_ + w.gact, W_ + w.lin, W_ + w.out, n, out_features, w.Pout, is_first, scale0,
+                                W_ + w.glin, out2));
+  return WIRE_OK;
+}
+
 extern "C" int wire_final_fwd(void* stream, const void* z, const void* Wf, const void* bf, int64_t n,
                               int in_features, int out_features, float* y, void* ws,
                               int64_t ws_bytes) {

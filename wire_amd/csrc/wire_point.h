@@ -38,7 +38,7 @@ hipError_t launch_final_reduce(hipStream_t s, int kind, float* part_w, float* pa
 // ---- fused final stage of a training step (wire, O <= 4): y = Re(z Wf^T + bf), MSE loss + dL/dy,
 // rec scatter, g_out = g_y conj(Wf), Gabor gradient of layer L, and the per-block partials of g_Wf /
 // g_bf in the SAME layout launch_final_bwd produces (FB_ROWS rows per block) for launch_final_reduce.
-bool final_fused_supported(int P);
+bool final_fused_supported(int P, int O);
 hipError_t launch_final_fused(hipStream_t s, const float* out, const float* lin, int64_t n, int P, int O,
                               const float* wf, const float* bfr, const float* target, const int64_t* idx,
                               int64_t first, float weight, float omega, float scale, float* y, float* rec,
@@ -114,3 +114,14 @@ hipError_t launch_pack3m(hipStream_t s, const float* W, const float* b, int K, i
                          float* Wb_fwd, float* Wb_dg, float* bias);
 hipError_t launch_wgrad3m_reduce(hipStream_t s, const float* slab, const float* bslab, int S, int K, int Kin,
                                  int Kp_o, int Kp_i, float* gW, float* gb);
+
+// ---- trainable omega_0 / scale_0 (ComplexGaborLayer(trainable=True), modules/wire.py:80-81):
+// out2 = { dL/d omega_0, dL/d scale_0 }; partial: 2 * hparam_blocks(n) floats
+int hparam_blocks(int64_t n);
+hipError_t launch_gabor_hparam_grad(hipStream_t s, const float* g, const float* lin, const float* out, int64_t n,
+                                    int K, int P, int is_first, float scale, float* partial, float* out2);
+
+// ---- best-so-far tracking on the device and the sigmoid of the mesh-export query
+hipError_t launch_track_best(hipStream_t s, const float* metric, float* best, int force, const float* src,
+                             float* dst, int64_t count, int* updated);
+hipError_t launch_sigmoid(hipStream_t s, float* x, int64_t count);

@@ -369,7 +369,12 @@ hipError_t launch_final_bwd(hipStream_t s, int kind, int raw, const float* g_y, 
 #define FF_MAXPASS 2      // P <= 1024 floats per row
 __global__ void mse_final_kernel(const float* __restrict__ partial, int nb, float lscale,
                                  float* __restrict__ loss_out);
-bool final_fused_supported(int P) { return (P % 64) == 0 && P <= 512 * FF_MAXPASS; }
+// (the kernel keeps 4 O P floats of W_f / partial sums in dynamic LDS: it must fit the 64 KB a launch gets
+// without an opt-in -- O = 4 with P = 1024 does not, and runs the unfused sequence instead)
+bool final_fused_supported(int P, int O) {
+  return (P % 64) == 0 && P <= 512 * FF_MAXPASS && O <= FF_MAXO &&
+         ((size_t)4 * O * P + 4 * (FF_MAXO + 1)) * sizeof(float) <= 65536;
+}
 
 template <int NPASS>
 __global__ __launch_bounds__(256) void final_fused_kernel(
@@ -528,7 +533,7 @@ hipError_t launch_final_fused(hipStream_t s, const float* out, const float* lin,
                               float* g_lin, float* part_w, float* part_b, float* loss_partial,
                               float* loss_out) {
   if (n <= 0) return hipSuccess;
-  if (O > FF_MAXO || !final_fused_supported(P)) return hipErrorInvalidValue;
+  if (!final_fused_supported(P, O)) return hipErrorInvalidValue;
   const int nblk = final_bwd_blocks(n);
   const float inv = (float)(1.0 / ((double)n * (double)O));
   const size_t shm = ((size_t)4 * O * P + 4 * (FF_MAXO + 1)) * sizeof(float);
@@ -1381,5 +1386,123 @@ hipError_t launch_wgrad3m_reduce(hipStream_t s, const float* slab, const float* 
                                  int Kp_o, int Kp_i, float* gW, float* gb) {
   dim3 grid(cdiv(Kin, 64), (unsigned)K);
   hipLaunchKernelGGL(wgrad3m_reduce_kernel, grid, dim3(256), 0, s, slab, bslab, S, K, Kin, Kp_o, Kp_i, gW, gb);
+  return hipGetLastError();
+}
+
+// ===========================================================================
+// trainable omega_0 / scale_0 of a ComplexGaborLayer (modules/wire.py:80-81, trainable=True):
+//   out = exp(j w0 lin - s0^2 |lin|^2)  =>  d out / d w0 = j lin out,  d out / d s0 = -2 s0 |lin|^2 out
+// and with c = conj(out) g (g = dL/dRe + j dL/dIm):
+//   dL/dw0 = sum Re(conj(g) j lin out) = sum (lin_re c_im - lin_im c_re),   dL/ds0 = -2 s0 sum |lin|^2 Re c.
+// lin: complex rows [n][P] blocked planar, or (is_first) real u [n][P/2]; g, out [n][P] blocked planar.
+// Two-stage deterministic reduction: partial[2][nblk] then one block.
+// ===========================================================================
+#define HP_ROWS 32
+__global__ __launch_bounds__(256) void gabor_hparam_partial_kernel(const float* __restrict__ g,
+                                                                   const float* __restrict__ lin,
+                                                                   const float* __restrict__ out, long long n, int K,
+                                                                   int P, int is_first, float* __restrict__ partial) {
+  __shared__ float red[2][256];
+  const long long r0 = (long long)blockIdx.x * HP_ROWS;
+  long long r1 = r0 + HP_ROWS;
+  if (r1 > n) r1 = n;
+  float aw = 0.f, as = 0.f;
+  for (long long row = r0; row < r1; ++row)
+    for (int f = threadIdx.x; f < K; f += 256) {
+      const size_t c = (size_t)row * P + blk_col(f, 0);
+      const float gr = g[c], gi = g[c + 32], pr = out[c], pi = out[c + 32];
+      float lr, li;
+      if (is_first) { lr = lin[(size_t)row * (P >> 1) + f]; li = 0.f; }
+      else { lr = lin[c]; li = lin[c + 32]; }
+      const float c_r = __builtin_fmaf(pr, gr, pi * gi);
+      const float c_i = __builtin_fmaf(pr, gi, -(pi * gr));
+      aw += __builtin_fmaf(lr, c_i, -(li * c_r));
+      as += __builtin_fmaf(lr, lr, li * li) * c_r;
+    }
+  red[0][threadIdx.x] = aw;
+  red[1][threadIdx.x] = as;
+  __syncthreads();
+  for (int sft = 128; sft >= 1; sft >>= 1) {
+    if ((int)threadIdx.x < sft) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + sft];
+      red[1][threadIdx.x] += red[1][threadIdx.x + sft];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = red[0][0];
+    partial[gridDim.x + blockIdx.x] = red[1][0];
+  }
+}
+__global__ __launch_bounds__(256) void gabor_hparam_final_kernel(const float* __restrict__ partial, int nblk,
+                                                                 float scale, float* __restrict__ out2) {
+  __shared__ float red[2][256];
+  float aw = 0.f, as = 0.f;
+  for (int b = threadIdx.x; b < nblk; b += 256) { aw += partial[b]; as += partial[nblk + b]; }
+  red[0][threadIdx.x] = aw;
+  red[1][threadIdx.x] = as;
+  __syncthreads();
+  for (int sft = 128; sft >= 1; sft >>= 1) {
+    if ((int)threadIdx.x < sft) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + sft];
+      red[1][threadIdx.x] += red[1][threadIdx.x + sft];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out2[0] = red[0][0];
+    out2[1] = -2.f * scale * red[1][0];
+  }
+}
+int hparam_blocks(int64_t n) { return (int)((n + HP_ROWS - 1) / HP_ROWS); }
+hipError_t launch_gabor_hparam_grad(hipStream_t s, const float* g, const float* lin, const float* out, int64_t n,
+                                    int K, int P, int is_first, float scale, float* partial, float* out2) {
+  if (n <= 0) return hipErrorInvalidValue;
+  const int nblk = hparam_blocks(n);
+  hipLaunchKernelGGL(gabor_hparam_partial_kernel, dim3((unsigned)nblk), dim3(256), 0, s, g, lin, out, (long long)n,
+                     K, P, is_first, partial);
+  hipLaunchKernelGGL(gabor_hparam_final_kernel, dim3(1), dim3(256), 0, s, partial, nblk, scale, out2);
+  return hipGetLastError();
+}
+
+// ===========================================================================
+// best-reconstruction tracking without a host round trip (wire_image_denoise.py:176-178:
+//   if (mse_array[epoch] < best_mse) or (epoch == 0): best_mse = ...; best_img = imrec
+// wire_occupancy.py:170-172: if lossval < best_mse: ...; best_img = copy.deepcopy(im_estim)).
+// Every thread reads the two scalars; the scalar itself is updated by a second one-thread launch.
+// ===========================================================================
+__global__ void best_copy_kernel(const float* __restrict__ metric, const float* __restrict__ best, int force,
+                                 const float* __restrict__ src, float* __restrict__ dst, long long count) {
+  if (!(force || metric[0] < best[0])) return;
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < count) {
+    *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(src + i);
+  } else {
+    for (long long j = i; j < count; ++j) dst[j] = src[j];
+  }
+}
+__global__ void best_scalar_kernel(const float* __restrict__ metric, float* __restrict__ best, int force,
+                                   int* __restrict__ updated) {
+  const bool take = force || metric[0] < best[0];
+  if (take) best[0] = metric[0];
+  if (updated) updated[0] = take ? 1 : 0;
+}
+hipError_t launch_track_best(hipStream_t s, const float* metric, float* best, int force, const float* src,
+                             float* dst, int64_t count, int* updated) {
+  if (count > 0)
+    hipLaunchKernelGGL(best_copy_kernel, dim3(cdiv(count, 1024)), dim3(256), 0, s, metric, best, force, src, dst,
+                       (long long)count);
+  hipLaunchKernelGGL(best_scalar_kernel, dim3(1), dim3(1), 0, s, metric, best, force, updated);
+  return hipGetLastError();
+}
+
+// torch.sigmoid of the dense occupancy query before the cube is written out (modules/volutils.py:128-131)
+__global__ void sigmoid_kernel(float* __restrict__ x, long long count) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) x[i] = 1.f / (1.f + wire_exp(-x[i]));
+}
+hipError_t launch_sigmoid(hipStream_t s, float* x, int64_t count) {
+  if (count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(sigmoid_kernel, dim3(cdiv(count, 256)), dim3(256), 0, s, x, (long long)count);
   return hipGetLastError();
 }

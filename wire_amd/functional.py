@@ -82,7 +82,9 @@ class _INRFunction(torch.autograd.Function):
                                   gy.data_ptr(), ctx.act.data_ptr(), ctx.act.numel(),
                                   scratch.data_ptr(), sbytes,
                                   _lib.ptr_array([g.data_ptr() for g in grads])), "wire_mlp_bwd")
-        ctx.act = ctx.packed = None
+        # the saved buffers stay with the graph node (freed with it), so backward(retain_graph=True) can run again.
+        # No gradient is returned for `coords` (the reference's autograd would produce one; no caller in the
+        # reference asks for it -- INTEGRATION.md)
         return (None, None, *grads)
 
 
@@ -134,6 +136,48 @@ class _GaborLayerFunction(torch.autograd.Function):
 
 def gabor_layer(x, W, b, omega0: float, scale0: float, is_first: bool):
     return _GaborLayerFunction.apply(x, W, b, float(omega0), float(scale0), bool(is_first))
+
+
+class _GaborLayerTrainableFunction(torch.autograd.Function):
+    """ComplexGaborLayer with trainable omega_0 / scale_0 (modules/wire.py:80-81, trainable=True):
+    wire_gabor_fwd / wire_gabor_bwd + wire_gabor_hparam_grad."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, omega, scale, is_first: bool):
+        omega0, scale0 = float(omega.detach().reshape(-1)[0]), float(scale.detach().reshape(-1)[0])
+        with torch.no_grad():
+            act = _GaborLayerFunction.apply(x.detach(), W.detach(), b.detach(), omega0, scale0, is_first)
+        in_f = W.shape[1]
+        xin = x.detach().to(torch.float32 if is_first else torch.complex64).contiguous()
+        ctx.save_for_backward(xin, _native(W), _native(b))
+        ctx.cfg = (omega0, scale0, is_first, xin.numel() // in_f, in_f, W.shape[0], tuple(x.shape), omega.shape,
+                   scale.shape)
+        return act
+
+    @staticmethod
+    def backward(ctx, g_act):
+        L = _lib.lib()
+        xin, Wn, bn = ctx.saved_tensors
+        omega0, scale0, is_first, n, in_f, out_f, xshape, oshape, sshape = ctx.cfg
+        dev = g_act.device
+        g = g_act.detach().to(torch.complex64).contiguous()
+        ws_bytes = _lib.check(L.wire_layer_ws_bytes(n, in_f, out_f), "wire_layer_ws_bytes")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        gW, gb = torch.empty_like(Wn), torch.empty_like(bn)
+        gx = None if is_first else torch.empty(xshape, dtype=torch.complex64, device=dev)
+        stream = _stream_ptr(dev)
+        _lib.check(L.wire_gabor_bwd(stream, g.data_ptr(), xin.data_ptr(), Wn.data_ptr(), bn.data_ptr(), omega0,
+                                    scale0, n, in_f, out_f, int(is_first), None if gx is None else gx.data_ptr(),
+                                    gW.data_ptr(), gb.data_ptr(), ws.data_ptr(), ws_bytes), "wire_gabor_bwd")
+        hp = torch.empty(2, dtype=torch.float32, device=dev)
+        _lib.check(L.wire_gabor_hparam_grad(stream, g.data_ptr(), xin.data_ptr(), Wn.data_ptr(), bn.data_ptr(),
+                                            omega0, scale0, n, in_f, out_f, int(is_first), hp.data_ptr(),
+                                            ws.data_ptr(), ws_bytes), "wire_gabor_hparam_grad")
+        return gx, gW, gb, hp[0].reshape(oshape), hp[1].reshape(sshape), None
+
+
+def gabor_layer_trainable(x, W, b, omega: torch.Tensor, scale: torch.Tensor, is_first: bool):
+    return _GaborLayerTrainableFunction.apply(x, W, b, omega, scale, bool(is_first))
 
 
 class _Gabor2DLayerFunction(torch.autograd.Function):

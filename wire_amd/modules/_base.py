@@ -48,17 +48,43 @@ class HipINR(nn.Module):
 
     def _finish(self, layers: List[nn.Module], in_features: int, width: int, hidden_layers: int,
                 out_features: int, first_omega_0: float, hidden_omega_0: float, scale: float,
-                posenc_freqs: int = 0) -> None:
+                posenc_freqs: int = 0, outermost_linear: bool = True) -> None:
         self.net = nn.Sequential(*layers)
         self._arch = dict(in_features=int(in_features), width=int(width),
                           hidden_layers=int(hidden_layers), out_features=int(out_features),
                           first_omega0=float(first_omega_0), hidden_omega0=float(hidden_omega_0),
                           scale0=float(scale), posenc_freqs=int(posenc_freqs))
+        # outermost_linear=False (modules/siren.py:81-84, gauss.py:63-66, relu.py:116-119): the last module is
+        # one more activation layer (K -> O).  The fused whole-net path ends in a linear layer, so such a net
+        # runs layer by layer through the per-layer HIP entry points (same kernels, one autograd node each).
+        self._layerwise = not outermost_linear
+        if any(isinstance(getattr(m, "omega_0", None), nn.Parameter) for m in layers):
+            # omega_0 / scale_0 live in the state_dict (modules/wire.py:80-81, wire2d.py:44-45): a checkpoint
+            # or a manual edit must reach the fused path's descriptor
+            self.register_load_state_dict_post_hook(lambda m, _keys: m.refresh_hparams())
+
+    def refresh_hparams(self) -> None:
+        """Re-read omega_0 / scale_0 from the layers' Parameters into the fused path's descriptor (after
+        ``load_state_dict`` -- done automatically -- or a manual edit such as ``net[0].omega_0.fill_()``).
+        One host sync; not on the hot path.  The fused kernels take ONE first-layer omega, one hidden omega and
+        one scale: per-layer values that differ raise."""
+        acts = [m for m in self.net if isinstance(getattr(m, "omega_0", None), nn.Parameter)]
+        if not acts:
+            return
+        for m in acts:
+            m.refresh_hparams()
+        self._arch["first_omega0"] = acts[0]._w
+        self._arch["scale0"] = acts[0]._s
+        if len(acts) > 1:
+            self._arch["hidden_omega0"] = acts[1]._w
+            if len({m._s for m in acts}) > 1 or len({m._w for m in acts[1:]}) > 1:
+                raise NotImplementedError("per-layer omega_0 / scale_0 values differ; the fused path supports one "
+                                          "first-layer omega, one hidden omega and one scale")
 
     # -- descriptor ---------------------------------------------------------
     def _layer_hparams(self):
-        """Read omega/scale back from the layer modules, so edits made after
-        construction (e.g. ``model.net[0].omega_0.fill_()``) are honoured."""
+        """omega / scale of the fused path's descriptor: the constructor's values, replaced by the layers'
+        ``omega_0`` / ``scale_0`` Parameters whenever ``refresh_hparams`` runs (load_state_dict does)."""
         return self._arch["first_omega0"], self._arch["hidden_omega0"], self._arch["scale0"]
 
     def net_desc(self) -> _lib.NetDesc:
@@ -78,6 +104,19 @@ class HipINR(nn.Module):
         return out
 
     def forward(self, coords: torch.Tensor) -> torch.Tensor:
+        if getattr(self, "pos_encode", False) and self._layerwise:
+            coords = self.positional_encoding(coords)
+        if self._layerwise or any(getattr(m, "trainable", False) for m in self.net):
+            out = coords
+            for m in self.net:
+                if isinstance(m, FinalLinear):      # Re(z W_f^T + b_f) (modules/wire.py:156-157,164-165)
+                    if not m.weight.is_complex():
+                        raise NotImplementedError("layer-by-layer execution ends in an activation layer or in the "
+                                                  "complex final linear of wire / wire2d")
+                    out = Fh.final_linear_real(out, m.weight, m.bias)
+                else:
+                    out = m(out)
+            return out
         return Fh.inr_forward(coords, self.net_desc(), self.param_tensors())
 
 

@@ -40,8 +40,6 @@ class INR(HipINR):
                  outermost_linear=True, first_omega_0=30, hidden_omega_0=30., scale=10.0,
                  pos_encode=False, sidelength=512, fn_samples=None, use_nyquist=True):
         super().__init__()
-        if not outermost_linear:
-            raise NotImplementedError("outermost_linear=False is not implemented in wire_amd")
         self.pos_encode = pos_encode
         self.complex = False
         self.nonlin = GaussLayer
@@ -49,6 +47,10 @@ class INR(HipINR):
                              scale=scale)]
         layers += [GaussLayer(hidden_features, hidden_features, is_first=False,
                               omega_0=hidden_omega_0, scale=scale) for _ in range(hidden_layers)]
-        layers.append(FinalLinear(hidden_features, out_features, dtype=torch.float))
+        if outermost_linear:
+            layers.append(FinalLinear(hidden_features, out_features, dtype=torch.float))
+        else:                                   # modules/gauss.py:63-66
+            layers.append(GaussLayer(hidden_features, out_features, is_first=False, omega_0=hidden_omega_0,
+                                     scale=scale))
         self._finish(layers, in_features, hidden_features, hidden_layers, out_features,
-                     first_omega_0, hidden_omega_0, scale)
+                     first_omega_0, hidden_omega_0, scale, outermost_linear=outermost_linear)

@@ -82,8 +82,6 @@ class INR(HipINR):
                  outermost_linear=True, first_omega_0=30, hidden_omega_0=30., scale=10.0,
                  pos_encode=False, sidelength=512, fn_samples=None, use_nyquist=True):
         super().__init__()
-        if not outermost_linear:
-            raise NotImplementedError("outermost_linear=False is not implemented in wire_amd")
         self.pos_encode = pos_encode
         self.complex = False
         self.nonlin = ReLULayer
@@ -98,6 +96,10 @@ class INR(HipINR):
                             scale=scale)]
         layers += [ReLULayer(hidden_features, hidden_features, is_first=False,
                              omega_0=hidden_omega_0, scale=scale) for _ in range(hidden_layers)]
-        layers.append(FinalLinear(hidden_features, out_features, dtype=torch.float))
+        if outermost_linear:
+            layers.append(FinalLinear(hidden_features, out_features, dtype=torch.float))
+        else:                                   # modules/relu.py:116-119
+            layers.append(ReLULayer(hidden_features, out_features, is_first=False, omega_0=hidden_omega_0,
+                                    scale=scale))
         self._finish(layers, in_features, hidden_features, hidden_layers, out_features,
-                     first_omega_0, hidden_omega_0, scale, posenc_freqs=freqs)
+                     first_omega_0, hidden_omega_0, scale, posenc_freqs=freqs, outermost_linear=outermost_linear)

@@ -53,18 +53,20 @@ class INR(HipINR):
         if pos_encode:
             raise NotImplementedError("the reference's siren.INR has no positional_encoding "
                                       "attribute either (modules/siren.py:91-92 would raise)")
-        if not outermost_linear:
-            raise NotImplementedError("outermost_linear=False is not implemented in wire_amd")
         self.pos_encode = pos_encode
         self.nonlin = SineLayer
         layers = [SineLayer(in_features, hidden_features, is_first=True, omega_0=first_omega_0,
                             scale=scale)]
         layers += [SineLayer(hidden_features, hidden_features, is_first=False,
                              omega_0=hidden_omega_0, scale=scale) for _ in range(hidden_layers)]
-        final = FinalLinear(hidden_features, out_features, dtype=torch.float)
-        with torch.no_grad():
-            const = np.sqrt(6 / hidden_features) / max(hidden_omega_0, 1e-12)
-            final.weight.uniform_(-const, const)
-        layers.append(final)
+        if outermost_linear:
+            final = FinalLinear(hidden_features, out_features, dtype=torch.float)
+            with torch.no_grad():
+                const = np.sqrt(6 / hidden_features) / max(hidden_omega_0, 1e-12)
+                final.weight.uniform_(-const, const)
+            layers.append(final)
+        else:                                   # modules/siren.py:81-84
+            layers.append(SineLayer(hidden_features, out_features, is_first=False, omega_0=hidden_omega_0,
+                                    scale=scale))
         self._finish(layers, in_features, hidden_features, hidden_layers, out_features,
-                     first_omega_0, hidden_omega_0, scale)
+                     first_omega_0, hidden_omega_0, scale, outermost_linear=outermost_linear)

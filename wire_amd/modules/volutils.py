@@ -1,0 +1,58 @@
+"""Volume helpers on the hot path's contract (reference modules/volutils.py).
+
+Only what the occupancy training / evaluation loop touches (wire_occupancy.py:160-172): the IoU metric.  Mesh
+extraction (marching cubes, open3d), noise models and SSIM helpers are out of scope.
+The counts are reduced on the device (wire_eval_metric mode 1): no host pass over the 134 M voxels of a 512^3
+volume.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def get_I_and_U(preds, gt, thres=None):
+    """Intersection and union counts (modules/volutils.py:78-91).  As in the reference, ``preds`` is binarised
+    IN PLACE when ``thres`` is given -- the caller's tensor afterwards holds 0 / 1 (wire_occupancy.py keeps that
+    binarised volume as ``best_img``).  CUDA float32 tensors take the device reduction; numpy arrays the
+    reference's own numpy expression."""
+    if isinstance(preds, np.ndarray):
+        if thres is not None:
+            preds[preds < thres] = 0.0
+            preds[preds >= thres] = 1.0
+        return np.logical_and(preds, gt).sum(), np.logical_or(preds, gt).sum()
+    if not preds.is_cuda:
+        raise _lib.WireHipError("get_I_and_U: tensors must be on the MI355X ('cuda'); wire_amd has no CPU path")
+    L = _lib.lib()
+    p = preds.detach()
+    g = gt.detach().to(p.device, torch.float32).contiguous()
+    if thres is not None:
+        p.masked_fill_(p < thres, 0.0)
+        p.masked_fill_(p >= thres, 1.0)
+    # without a threshold the reference's logical_and / logical_or test for non-zero (either sign)
+    flat = p.to(torch.float32).contiguous() if thres is not None else (p != 0).to(torch.float32).contiguous()
+    out = torch.empty(2, dtype=torch.float32, device=p.device)
+    partial = torch.empty(4096, dtype=torch.float32, device=p.device)
+    # the volume now holds 0 / 1: counting "pred >= 0.5" counts its ones
+    _lib.check(L.wire_eval_metric(torch.cuda.current_stream(p.device).cuda_stream, 1, flat.data_ptr(), g.data_ptr(),
+                                  flat.numel(), 0.5, out.data_ptr(), partial.data_ptr()), "wire_eval_metric")
+    return out[0], out[1]
+
+
+def get_IoU(preds, gt, thres=None):
+    """modules/volutils.py:74-76."""
+    intersection, union = get_I_and_U(preds, gt, thres)
+    return intersection / union
+
+
+def get_IoU_batch(preds, gt, thres=None, maxpoints=int(50e6)):
+    """modules/volutils.py:54-71: IoU accumulated over slabs of ``maxpoints`` voxels."""
+    preds, gt = preds.flatten(), gt.flatten()
+    inter, union = [], []
+    for b in range(0, preds.numel(), maxpoints):
+        i, u = get_I_and_U(preds[b:b + maxpoints], gt[b:b + maxpoints], thres)
+        inter.append(i)
+        union.append(u)
+    return sum(inter) / sum(union)

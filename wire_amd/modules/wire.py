@@ -30,10 +30,7 @@ class ComplexGaborLayer(ActivationLayer):
     def __init__(self, in_features, out_features, bias=True, is_first=False,
                  omega0=10.0, sigma0=40.0, trainable=False):
         super().__init__()
-        if trainable:
-            raise NotImplementedError(
-                "trainable omega_0/scale_0 is not implemented in wire_amd (the reference's INR "
-                "never enables it: modules/wire.py:134,140)")
+        self.trainable = bool(trainable)
         self.is_first = is_first
         self.in_features = in_features
         # same creation order as the reference so the RNG stream lines up
@@ -51,6 +48,11 @@ class ComplexGaborLayer(ActivationLayer):
         return [self.linear.weight, self._bias_or_zeros(self.linear)]
 
     def forward(self, input):
+        if self.trainable:
+            # omega_0 / scale_0 receive gradients (modules/wire.py:80-81 with trainable=True): their current
+            # values are read per call (one host sync) and two column sums are added to the backward
+            return Fh.gabor_layer_trainable(input, self.linear.weight, self._bias_or_zeros(self.linear),
+                                            self.omega_0, self.scale_0, self.is_first)
         return Fh.gabor_layer(input, self.linear.weight, self._bias_or_zeros(self.linear),
                               self._w, self._s, self.is_first)
 
@@ -78,21 +80,3 @@ class INR(HipINR):
         layers.append(FinalLinear(width, out_features, dtype=torch.cfloat))
         self._finish(layers, in_features, width, hidden_layers, out_features,
                      first_omega_0, hidden_omega_0, scale)
-        self.register_load_state_dict_post_hook(lambda m, _keys: m.refresh_hparams())
-
-    def refresh_hparams(self):
-        """Re-read omega_0 / scale_0 from the layer parameters (after
-        load_state_dict or a manual edit).  One host sync; not on the hot path."""
-        for m in self.net:
-            if isinstance(m, ComplexGaborLayer):
-                m.refresh_hparams()
-        L = self._arch["hidden_layers"]
-        self._arch["first_omega0"] = self.net[0]._w
-        self._arch["scale0"] = self.net[0]._s
-        if L > 0:
-            self._arch["hidden_omega0"] = self.net[1]._w
-            scales = {self.net[i]._s for i in range(L + 1)}
-            omegas = {self.net[i]._w for i in range(1, L + 1)}
-            if len(scales) > 1 or len(omegas) > 1:
-                raise NotImplementedError("per-layer omega/scale values differ; the fused path "
-                                          "supports one hidden omega and one scale")

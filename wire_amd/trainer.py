@@ -325,11 +325,35 @@ class FusedTrainer:
                                            out.data_ptr(), self.partial.data_ptr()), "metric")
         return out
 
+    # ------------------------------------------------------------------ best-so-far tracking
+    def update_best(self, metric: torch.Tensor, image: torch.Tensor, force: bool = False) -> None:
+        """Device-side restatement of the drivers' best-result bookkeeping -- ``if (mse_array[epoch] < best_mse) or
+        (epoch == 0): best_mse = mse_array[epoch]; best_img = imrec`` (wire_image_denoise.py:176-178; pass
+        ``force=(epoch == 0)``) and ``if lossval < best_mse: ...; best_img = copy.deepcopy(im_estim)``
+        (wire_occupancy.py:170-172): ``metric`` is a 1-element device tensor (an MSE, ``tr.loss`` ...), ``image`` the
+        reconstruction (``tr.rec``, a render).  No ``.item()``, no per-epoch copy of the image to the host: a
+        compare-and-copy kernel keeps ``self.best_metric`` / ``self.best_img`` current."""
+        img = image.detach()
+        if not img.is_cuda or img.dtype != torch.float32 or not img.is_contiguous():
+            raise ValueError("image must be a contiguous CUDA float32 tensor")
+        m = metric.detach().reshape(-1)
+        if not m.is_cuda or m.dtype != torch.float32 or m.numel() != 1:
+            raise ValueError("metric must be a 1-element CUDA float32 tensor")
+        if getattr(self, "best_img", None) is None or self.best_img.numel() != img.numel():
+            self.best_img = torch.zeros_like(img)
+            self.best_metric = torch.full((1,), float("inf"), dtype=torch.float32, device=self.dev)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        _lib.check(self.L.wire_track_best(stream, m.data_ptr(), self.best_metric.data_ptr(), int(bool(force)),
+                                          img.data_ptr(), self.best_img.data_ptr(), img.numel(), None), "track_best")
+
     # ------------------------------------------------------------------ inference
     @torch.no_grad()
-    def render(self, first: int = 0, count: Optional[int] = None, tile: int = 1 << 20) -> torch.Tensor:
+    def render(self, first: int = 0, count: Optional[int] = None, tile: int = 1 << 20,
+               sigmoid: bool = False) -> torch.Tensor:
         """Forward-only dense query of grid rows [first, first+count) in tiles
-        (no saved activations): the reference's full-image / volume evaluation."""
+        (no saved activations): the reference's full-image / volume evaluation.  ``sigmoid=True`` applies
+        ``torch.sigmoid`` to the result, the occupancy cube ``export_mesh`` hands to marching cubes
+        (modules/volutils.py:124-133; the meshing itself is out of scope)."""
         L, d = self.L, C.byref(self.desc)
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         count = int(count if count is not None else self.npoints - first)
@@ -348,4 +372,6 @@ class FusedTrainer:
                                                 coords.data_ptr()), "coords")
             _lib.check(L.wire_mlp_fwd(stream, d, self.packed.data_ptr(), coords.data_ptr(), n,
                                       out.data_ptr() + 4 * s * self.O, act.data_ptr(), ab, 0), "fwd")
+        if sigmoid:
+            _lib.check(L.wire_sigmoid_inplace(stream, out.data_ptr(), out.numel()), "sigmoid")
         return out
