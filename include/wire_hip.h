@@ -228,6 +228,14 @@ int wire_eval_metric(void* stream, int mode, const float* rec, const float* gt,
  * and metric[0] to best_metric[0]; updated (optional, device int) receives 1 / 0.  All pointers device.      */
 int wire_track_best(void* stream, const float* metric, float* best_metric, int force, const float* src,
                     float* dst, int64_t count, int* updated);
+/* CT forward operator of wire_ct.py:128-133 -- lin_inverse.radon (modules/lin_inverse.py:19-40): every angle
+ * rotates the image (kornia.geometry.rotate of kornia 0.6.5: about ((W-1)/2, (H-1)/2), counter-clockwise degrees,
+ * bilinear, zero padding, align_corners) and sums over the rows: img [H][W] -> sino [nangles][W].  wire_radon_bwd
+ * is its adjoint, g_sino [nangles][W] -> g_img [H][W] (overwritten; float atomics: summation order, hence the last
+ * bits, vary from run to run).                                                                              */
+int wire_radon_fwd(void* stream, const float* img, const float* angles_deg, int H, int W, int nangles, float* sino);
+int wire_radon_bwd(void* stream, const float* g_sino, const float* angles_deg, int H, int W, int nangles,
+                   float* g_img);
 /* torch.sigmoid of the dense occupancy query before the cube is written (modules/volutils.py:128-131)       */
 int wire_sigmoid_inplace(void* stream, float* x, int64_t count);
 

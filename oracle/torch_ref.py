@@ -167,3 +167,31 @@ def driver_loop(p: TParams, coords: torch.Tensor, gt: torch.Tensor, hidden_layer
         if metric < best or (epoch == 0 and not squeeze_occupancy):
             best, best_img = metric, rec.clone()
     return losses, rec, best_img, {k: v.detach() for k, v in params.items()}
+
+
+def radon(imten: torch.Tensor, angles_deg: torch.Tensor) -> torch.Tensor:
+    """lin_inverse.radon (modules/lin_inverse.py:19-40) for one image: imten [H, W] -> sinogram [nangles, W].
+
+    The reference rotates with ``kornia.geometry.rotate`` (pinned kornia==0.6.5, requirements.txt:6; kornia is
+    not installed here).  Its published algorithm, restated with the ATen ops it dispatches:
+    ``get_rotation_matrix2d`` about ((W-1)/2, (H-1)/2), positive angle counter-clockwise; ``warp_affine`` =
+    ``normalize_homography`` with (W-1, H-1), inverse, ``F.affine_grid`` + ``F.grid_sample`` (bilinear, zeros,
+    align_corners=True); then ``.sum`` over the rows.  Pinned by the gt -> sinogram pair the reference stores in
+    multiscale_results/ct/Original/WIRE_s12_o8_LR5e3_E2000_1/info.mat (tests/golden/ct_pair.npz): max |diff|
+    1e-4 on values up to 47 (the stored run was fp32 on the authors' GPU)."""
+    H, W = imten.shape
+    dt = imten.dtype
+    a = torch.deg2rad(angles_deg.to(dt))
+    c, s = torch.cos(a), torch.sin(a)
+    cx, cy = (W - 1) / 2.0, (H - 1) / 2.0
+    M = torch.zeros(len(a), 3, 3, dtype=dt)
+    M[:, 0, 0], M[:, 0, 1], M[:, 0, 2] = c, s, (1 - c) * cx - s * cy
+    M[:, 1, 0], M[:, 1, 1], M[:, 1, 2] = -s, c, s * cx + (1 - c) * cy
+    M[:, 2, 2] = 1
+    N = torch.tensor([[2.0 / (W - 1), 0, -1], [0, 2.0 / (H - 1), -1], [0, 0, 1]], dtype=dt)
+    Mn = N @ M @ torch.linalg.inv(N)
+    theta = torch.linalg.inv(Mn)[:, :2, :]
+    grid = F.affine_grid(theta, [len(a), 1, H, W], align_corners=True)
+    rot = F.grid_sample(imten[None, None].expand(len(a), 1, H, W), grid, mode="bilinear", padding_mode="zeros",
+                        align_corners=True)
+    return rot.sum(2)[:, 0, :]

@@ -302,9 +302,25 @@ def misc2():
     print("misc2: iou =", rec["iou_val"], "trainable g_omega (hid) =", rec["tr_hid_g_omega"], rec["tr_hid_g_omega64"])
 
 
+def ct_pair():
+    """The reference holds one input/output pair of its CT forward operator (lin_inverse.radon, which needs kornia):
+    the phantom ``gt`` and its ``sinogram`` over np.linspace(0, 180, 100) degrees, saved by wire_ct.py:160-163 into
+    multiscale_results/ct/Original/WIRE_s12_o8_LR5e3_E2000_1/info.mat.  Data only: copied into a fixture."""
+    from scipy.io import loadmat
+    d = loadmat(os.path.join(REF, "multiscale_results/ct/Original/WIRE_s12_o8_LR5e3_E2000_1/info.mat"))
+    r = d[[k for k in d if not k.startswith("__")][0]][0, 0]
+    gt, sino = r["gt"].astype(np.float32), r["sinogram"].astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "ct_pair.npz"), gt=gt, sinogram=sino,
+                        thetas=np.linspace(0, 180, sino.shape[0], dtype=np.float32))
+    print("ct_pair:", gt.shape, sino.shape)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "misc2":
         misc2()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ct_pair":
+        ct_pair()
         sys.exit(0)
     N = 512
     # ---- small, everything stored
@@ -334,3 +350,4 @@ if __name__ == "__main__":
              pos_encode=True, sidelength=512)
     misc()
     misc2()
+    ct_pair()

@@ -682,6 +682,20 @@ extern "C" int wire_track_best(void* stream, const float* metric, float* best_me
   HIPCHK(launch_track_best((hipStream_t)stream, metric, best_metric, force, src, dst, count, updated));
   return WIRE_OK;
 }
+extern "C" int wire_radon_fwd(void* stream, const float* img, const float* angles_deg, int H, int W, int nangles,
+                              float* sino) {
+  if (H < 1 || W < 1 || nangles < 1 || !img || !angles_deg || !sino) return fail(WIRE_ERR_ARG, "bad argument to wire_radon_fwd");
+  ProfScope ps((hipStream_t)stream, 3, 0);
+  HIPCHK(launch_radon_fwd((hipStream_t)stream, img, angles_deg, H, W, nangles, sino));
+  return WIRE_OK;
+}
+extern "C" int wire_radon_bwd(void* stream, const float* g_sino, const float* angles_deg, int H, int W, int nangles,
+                              float* g_img) {
+  if (H < 1 || W < 1 || nangles < 1 || !g_sino || !angles_deg || !g_img) return fail(WIRE_ERR_ARG, "bad argument to wire_radon_bwd");
+  ProfScope ps((hipStream_t)stream, 3, 0);
+  HIPCHK(launch_radon_bwd((hipStream_t)stream, g_sino, angles_deg, H, W, nangles, g_img));
+  return WIRE_OK;
+}
 extern "C" int wire_sigmoid_inplace(void* stream, float* x, int64_t count) {
   if (count < 0 || (count > 0 && !x)) return fail(WIRE_ERR_ARG, "bad argument to wire_sigmoid_inplace");
   HIPCHK(launch_sigmoid((hipStream_t)stream, x, count));

@@ -125,3 +125,8 @@ hipError_t launch_gabor_hparam_grad(hipStream_t s, const float* g, const float* 
 hipError_t launch_track_best(hipStream_t s, const float* metric, float* best, int force, const float* src,
                              float* dst, int64_t count, int* updated);
 hipError_t launch_sigmoid(hipStream_t s, float* x, int64_t count);
+
+// ---- CT forward operator: rotate-and-sum Radon transform (modules/lin_inverse.py:19-40) and its adjoint
+hipError_t launch_radon_fwd(hipStream_t s, const float* img, const float* angles, int H, int W, int A, float* sino);
+hipError_t launch_radon_bwd(hipStream_t s, const float* g_sino, const float* angles, int H, int W, int A,
+                            float* g_img);

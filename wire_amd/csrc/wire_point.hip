@@ -1506,3 +1506,79 @@ hipError_t launch_sigmoid(hipStream_t s, float* x, int64_t count) {
   hipLaunchKernelGGL(sigmoid_kernel, dim3(cdiv(count, 256)), dim3(256), 0, s, x, (long long)count);
   return hipGetLastError();
 }
+
+// ===========================================================================
+// CT forward operator (modules/lin_inverse.py:19-40, wire_ct.py:128-133): the parallel-beam Radon transform the
+// reference builds from kornia.geometry.rotate (kornia 0.6.5: get_rotation_matrix2d about ((W-1)/2, (H-1)/2),
+// positive angle = counter-clockwise, warp_affine -> affine_grid + grid_sample, bilinear, zero padding,
+// align_corners = True) followed by a sum over the rows:
+//     sino[a][j] = sum_i  bilinear(img, x = c (j - cx) - s (i - cy) + cx,  y = s (j - cx) + c (i - cy) + cy)
+// with c = cos(theta_a), s = sin(theta_a).  Samples within one pixel outside the image interpolate against zero.
+// Pinned by the gt -> sinogram pair the reference stores (multiscale_results/ct/.../info.mat).
+// Forward: one thread per (angle, column), rows in the loop -> reads of a row walk a straight line of the image.
+// Backward (the adjoint, for dL/dimg): same traversal, four atomic adds per sample.
+// ===========================================================================
+template <bool BWD>
+__global__ __launch_bounds__(256) void radon_kernel(const float* __restrict__ img, const float* __restrict__ angles,
+                                                    int H, int W, int A, float* __restrict__ sino,
+                                                    const float* __restrict__ g_sino, float* __restrict__ g_img) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int a = blockIdx.y;
+  if (j >= W) return;
+  const float th = angles[a] * 0.017453292519943295f;
+  float sn, cs;
+  wire_sincos(th, sn, cs);
+  const float cx = 0.5f * (float)(W - 1), cy = 0.5f * (float)(H - 1);
+  const float xj = (float)j - cx;
+  const float g = BWD ? g_sino[(size_t)a * W + j] : 0.f;
+  float acc = 0.f;
+  for (int i = 0; i < H; ++i) {
+    const float yi = (float)i - cy;
+    const float x = __builtin_fmaf(cs, xj, -(sn * yi)) + cx;
+    const float y = __builtin_fmaf(sn, xj, cs * yi) + cy;
+    const float xf = floorf(x), yf = floorf(y);
+    const int x0 = (int)xf, y0 = (int)yf;
+    if (x0 < -1 || x0 >= W || y0 < -1 || y0 >= H) continue;
+    const float wx1 = x - xf, wy1 = y - yf, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const bool vx0 = x0 >= 0, vx1 = x0 + 1 < W, vy0 = y0 >= 0, vy1 = y0 + 1 < H;
+    if (!BWD) {
+      float v = 0.f;
+      if (vy0) {
+        const float* r = img + (size_t)y0 * W;
+        if (vx0) v += wy0 * wx0 * r[x0];
+        if (vx1) v += wy0 * wx1 * r[x0 + 1];
+      }
+      if (vy1) {
+        const float* r = img + (size_t)(y0 + 1) * W;
+        if (vx0) v += wy1 * wx0 * r[x0];
+        if (vx1) v += wy1 * wx1 * r[x0 + 1];
+      }
+      acc += v;
+    } else {
+      if (vy0) {
+        float* r = g_img + (size_t)y0 * W;
+        if (vx0) atomicAdd(r + x0, g * wy0 * wx0);
+        if (vx1) atomicAdd(r + x0 + 1, g * wy0 * wx1);
+      }
+      if (vy1) {
+        float* r = g_img + (size_t)(y0 + 1) * W;
+        if (vx0) atomicAdd(r + x0, g * wy1 * wx0);
+        if (vx1) atomicAdd(r + x0 + 1, g * wy1 * wx1);
+      }
+    }
+  }
+  if (!BWD) sino[(size_t)a * W + j] = acc;
+}
+hipError_t launch_radon_fwd(hipStream_t s, const float* img, const float* angles, int H, int W, int A, float* sino) {
+  dim3 grid(cdiv(W, 256), (unsigned)A);
+  hipLaunchKernelGGL(radon_kernel<false>, grid, dim3(256), 0, s, img, angles, H, W, A, sino, nullptr, nullptr);
+  return hipGetLastError();
+}
+hipError_t launch_radon_bwd(hipStream_t s, const float* g_sino, const float* angles, int H, int W, int A,
+                            float* g_img) {
+  hipError_t e = hipMemsetAsync(g_img, 0, (size_t)H * W * sizeof(float), s);
+  if (e != hipSuccess) return e;
+  dim3 grid(cdiv(W, 256), (unsigned)A);
+  hipLaunchKernelGGL(radon_kernel<true>, grid, dim3(256), 0, s, nullptr, angles, H, W, A, nullptr, g_sino, g_img);
+  return hipGetLastError();
+}

@@ -297,6 +297,53 @@ class FusedTrainer:
         self.loss = g[self.count:self.count + 1].clone()
         return self.loss
 
+    # ------------------------------------------------------------------ CT step
+    def step_radon(self, sinogram: torch.Tensor, thetas: torch.Tensor) -> torch.Tensor:
+        """One optimizer step of the CT loop (wire_ct.py:128-139): the model is evaluated on the WHOLE grid in raster
+        order (``img_estim = model(coords).reshape(-1, H, W)``), ``lin_inverse.radon`` turns it into a sinogram
+        ([nangles, W]), loss = mean squared error against ``sinogram``; backward through the adjoint Radon kernel
+        and the network, Adam.  The image estimate of this step stays in ``self.y`` ([H*W, 1]).  2-D grids, one output
+        feature, single process."""
+        if self.tz is not None or len(self.grid) != 2 or self.O != 1:
+            raise ValueError("step_radon needs a 2-D grid and out_features == 1")
+        if self.world != 1:
+            raise NotImplementedError("step_radon is single-process")
+        H, W = int(self.grid[0]), int(self.grid[1])
+        th = thetas.detach().to(self.dev, torch.float32).contiguous()
+        A = th.numel()
+        tgt = sinogram.detach()
+        if not tgt.is_cuda or tgt.dtype != torch.float32 or tgt.numel() != A * W:
+            raise ValueError(f"sinogram must be a CUDA float32 tensor of {A} x {W} elements")
+        tgt = tgt.contiguous()
+        L, d = self.L, C.byref(self.desc)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        n = H * W
+        self._reserve(n)
+        if getattr(self, "_sino", None) is None or self._sino.numel() != A * W:
+            self._sino = torch.empty(A * W, dtype=torch.float32, device=self.dev)
+            self._gsino = torch.empty(A * W, dtype=torch.float32, device=self.dev)
+        g = self.gbuf[0]
+        _lib.check(L.wire_pack_params(stream, d, self.param_ptrs, self.packed.data_ptr()), "pack")
+        _lib.check(L.wire_coords_from_index(stream, None, 0, n, self.tx.data_ptr(), W, self.ty.data_ptr(), H,
+                                            None, 1, self.coords.data_ptr()), "coords")
+        _lib.check(L.wire_mlp_fwd(stream, d, self.packed.data_ptr(), self.coords.data_ptr(), n,
+                                  self.y.data_ptr(), self.act.data_ptr(), self.act_bytes, 1), "fwd")
+        _lib.check(L.wire_radon_fwd(stream, self.y.data_ptr(), th.data_ptr(), H, W, A, self._sino.data_ptr()), "radon")
+        _lib.check(L.wire_mse_grad(stream, self._sino.data_ptr(), tgt.data_ptr(), None, 0, A * W, 1, 1.0,
+                                   self._gsino.data_ptr(), g.data_ptr() + 4 * self.count, None,
+                                   self.partial.data_ptr()), "mse_grad")
+        _lib.check(L.wire_radon_bwd(stream, self._gsino.data_ptr(), th.data_ptr(), H, W, A, self.gy.data_ptr()),
+                   "radon_bwd")
+        _lib.check(L.wire_mlp_bwd(stream, d, self.packed.data_ptr(), self.coords.data_ptr(), n,
+                                  self.gy.data_ptr(), self.act.data_ptr(), self.act_bytes,
+                                  self.scratch.data_ptr(), self.scr_bytes, self.grad_ptrs[0]), "bwd")
+        self.t += 1
+        _lib.check(L.wire_adam_step_flat(stream, self.flat.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(),
+                                         self.exp_avg_sq.data_ptr(), self.count, self.current_lr(),
+                                         self.betas[0], self.betas[1], self.eps, self.t), "adam")
+        self.loss = g[self.count:self.count + 1].clone()
+        return self.loss
+
     @property
     def flat_grad(self) -> torch.Tensor:
         return self.gbuf[0][:self.count]
