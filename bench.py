@@ -28,8 +28,8 @@ The JSON line also carries
                  is 6 bf16 MFMA products, so the ceiling of the algorithm is
                  the dense bf16 MFMA peak / 6 = 416.7 fp32-equivalent TFLOP/s;
                  with WIRE_SPLIT_BF16=0 (fp32-MFMA kernels) it is 157.3.
-                 mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs ... per SIMD) of that
-                 kernel from the committed PMC summary (profiles/pmc_traffic.json).
+                 mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) of that kernel
+                 from the committed PMC summary (profiles/pmc_traffic.json; rocprofv3 --pmc in its own passes).
   cpu_baseline : the oracle's eager-PyTorch restatement of the reference's CPU
                  path (kind "port"), timed on this host's cores on a bounded
                  sample of the same workload.

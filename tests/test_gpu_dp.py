@@ -18,10 +18,10 @@ pytestmark = pytest.mark.gpu
 H, W = 24, 21            # 504 points: odd shard sizes with 2 ranks x 2 micro-shards
 
 
-def _make(dev, micro):
+def _make(dev, micro, seed=0):
     from wire_amd.modules import models
     from wire_amd.trainer import FusedTrainer
-    torch.manual_seed(0)
+    torch.manual_seed(seed)
     model = models.get_INR(nonlin="wire", in_features=2, out_features=3, hidden_features=64,
                            hidden_layers=2, first_omega_0=7.0, hidden_omega_0=7.0, scale=6.0).to(dev)
     g = torch.Generator().manual_seed(3)
@@ -29,28 +29,32 @@ def _make(dev, micro):
     return model, FusedTrainer(model, (H, W), target, lr=5e-3, niters=100, micro_shards=micro)
 
 
-def _run(tr, dev):
+def _run(tr, dev, hashed=False):
     g = torch.Generator().manual_seed(11)
     losses = []
     for it in range(4):
         perm = torch.randperm(H * W, generator=g)
         for b in range(0, H * W, 200):                       # 200 + 200 + 104 (ragged)
-            losses.append(tr.step(perm[b:b + 200].to(dev)))
+            if hashed:      # every rank evaluates only ITS slice of the epoch's position-keyed shuffle
+                losses.append(tr.step_hashed(it, first=b, count=min(200, H * W - b)))
+            else:
+                losses.append(tr.step(perm[b:b + 200].to(dev)))
         tr.scheduler_step()
     torch.cuda.synchronize()
     return [float(l.item()) for l in losses]
 
 
-def _worker(rank, world, port, micro, out_dir):
+def _worker(rank, world, port, micro, out_dir, hashed=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    model, tr = _make(dev, micro)
+    # hashed mode: the ranks are BUILT from different seeds -- FusedTrainer broadcasts rank 0's parameters
+    model, tr = _make(dev, micro, seed=100 + rank if hashed else 0)
     assert tr.world == world and tr.rank == rank
-    losses = _run(tr, dev)
+    losses = _run(tr, dev, hashed)
     flat = tr.flat.detach().cpu().numpy()
     np.save(os.path.join(out_dir, f"flat_{rank}.npy"), flat)
     np.save(os.path.join(out_dir, f"loss_{rank}.npy"), np.array(losses))
@@ -72,3 +76,17 @@ def test_two_ranks_match_single_process(tmp_path, micro):
     np.testing.assert_allclose(l0, ref_losses, rtol=2e-4)    # same trajectory as one process
     # parameters: Adam normalises the step, so compare against the step size
     assert np.abs(f0 - ref_flat).max() < 0.05 * 5e-3
+
+
+def test_two_ranks_hashed_shuffle_and_broadcast(tmp_path):
+    """step_hashed across two ranks == one process on the same positions of the shuffle; replicas built from
+    different seeds are made identical by the rank-0 broadcast in FusedTrainer.__init__."""
+    port = 29900 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(2, port, 1, str(tmp_path), True), nprocs=2, join=True)
+    dev = torch.device("cuda", 0)
+    model, tr = _make(dev, 1, seed=100)
+    ref_losses = _run(tr, dev, hashed=True)
+    f0, f1 = np.load(tmp_path / "flat_0.npy"), np.load(tmp_path / "flat_1.npy")
+    np.testing.assert_array_equal(f0, f1)
+    np.testing.assert_allclose(np.load(tmp_path / "loss_0.npy"), ref_losses, rtol=2e-4)
+    assert np.abs(f0 - tr.flat.detach().cpu().numpy()).max() < 0.05 * 5e-3

@@ -81,6 +81,8 @@ int main(int argc, char** argv) {
       {"x3g m1 store noDMA+noEPI", 1, EPI_STORE, -3}, {"x3g m1 store noREADS", 1, EPI_STORE, -4},
       {"x3g m1 store MFMA+VALU only", 1, EPI_STORE, -7},
       {"x3g m2 store noEPI", 2, EPI_STORE, -2}, {"x3g m2 store MFMA+VALU only", 2, EPI_STORE, -7},
+      {"x3g m3 (1 wave/SIMD) store", 3, EPI_STORE, 0}, {"x3g m3 store noEPI", 3, EPI_STORE, -2},
+      {"x3g m3 store MFMA+VALU only", 3, EPI_STORE, -7},
   };
   std::vector<double> best(vars.size(), 1e30), sum(vars.size(), 0);
   for (int r = 0; r < rounds + 1; ++r) {

@@ -272,7 +272,7 @@ static int g_x3_glds = x3g_env("WIRE_X3_GLDS", 0);
 static int g_x3_stagger = x3g_env("WIRE_X3_STAGGER", 0);          // ticks of the 100 MHz counter (100 = 1 us)
 static int g_x3_stagger_lo = x3g_env("WIRE_X3_STAGGER_LO", 256), g_x3_stagger_hi = x3g_env("WIRE_X3_STAGGER_HI", 512);
 int gemmx3g_tune_set(const char* key, int value) {
-  if (!strcmp(key, "x3_glds") && value >= 0 && value <= 2) { g_x3_glds = value; return 0; }
+  if (!strcmp(key, "x3_glds") && value >= 0 && value <= 3) { g_x3_glds = value; return 0; }
   if (!strcmp(key, "x3_stagger") && value >= 0) { g_x3_stagger = value; return 0; }
   if (!strcmp(key, "x3_stagger_lo") && value >= 0) { g_x3_stagger_lo = value; return 0; }
   if (!strcmp(key, "x3_stagger_hi") && value >= 0) { g_x3_stagger_hi = value; return 0; }
@@ -284,6 +284,7 @@ int gemmx3g_mode() { return g_x3_glds; }
 bool gemmx3g_handles(int epi, int64_t M) {
   if (!g_x3_glds || M < 4096) return false;
   if (epi == EPI_STORE || epi == EPI_GABOR_FWD || epi == EPI_GABOR_BWD || epi == EPI_GABOR_BWD_FIRST) return true;
+  if (g_x3_glds == 3) return false;
   return g_x3_glds == 1 && epi >= EPI_SIREN_FWD && epi <= EPI_GABOR2D_BWD_FIRST;
 }
 
@@ -295,6 +296,8 @@ hipError_t launch_gemmx3g_nt(hipStream_t s, int epi, const float* A, int lda, co
   if ((epi == EPI_GABOR_FWD || epi == EPI_GABOR_BWD) && ep.ld0 != ep.ld1) ep.wide = 1;
   if ((double)M * (double)(ep.ld1 > ep.ld0 ? ep.ld1 : ep.ld0) * 4.0 >= 4294967296.0) ep.wide = 1;
   ep.stagger = g_x3_stagger; ep.stagger_lo = g_x3_stagger_lo; ep.stagger_hi = g_x3_stagger_hi;
+  // mode 3 (probe): the mode-1 tile with 4 buffers = 112 KB of LDS -> ONE workgroup per CU, one wave per SIMD
+  if (g_x3_glds == 3 && epi == EPI_STORE) return launchx3g_t<EPI_STORE, 2, 4, 4, 1, 4>(s, A, lda, Bx3, M, Nc, Kd, ep);
 #define X3G_CASE(E)                                                                                  \
   case E:                                                                                            \
     return g_x3_glds == 2 ? launchx3g_t<E, 2, 4, 4, 2, 3>(s, A, lda, Bx3, M, Nc, Kd, ep)             \
