@@ -638,58 +638,70 @@ hipError_t launch_final_reduce(hipStream_t s, int kind, float* part_w, float* pa
 //   g_W = g_lin^T conj(z):  re = M[(o,re),(i,re)] + M[(o,im),(i,im)]
 //                           im = M[(o,im),(i,re)] - M[(o,re),(i,im)]
 // ===========================================================================
-__global__ void wgrad_reduce_kernel(int kind, const float* __restrict__ slab,
+// block = 64 input features x 4 groups of row splits (group q sums splits q, q + 4, ... with four loads in
+// flight); the four partial sums are combined through LDS in a fixed order (deterministic, no atomics).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(int kind, const float* __restrict__ slab,
                                     const float* __restrict__ bslab, int S, int K, int Kin, int Pm,
                                     int Pn, float* __restrict__ gW, float* __restrict__ gb,
                                     float* __restrict__ gV, float* __restrict__ gc) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float red[4][4][64];       // [value][group][feature]
+  const int tx = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + tx;
   const int o = blockIdx.y;
   const size_t sstride = (size_t)Pm * Pn;
-  if (kind == NK_WIRE || kind == NK_WIRE2D) {
-    const int nmat = (kind == NK_WIRE2D) ? 2 : 1;
-    for (int mat = 0; mat < nmat; ++mat) {
-      int r_re, r_im;
-      if (kind == NK_WIRE) {
-        r_re = blk_col(o, 0);
-        r_im = r_re + 32;
+  const bool cplx = (kind == NK_WIRE || kind == NK_WIRE2D);
+  const int nmat = (kind == NK_WIRE2D) ? 2 : 1;
+  for (int mat = 0; mat < nmat; ++mat) {
+    int r_re, r_im = 0;
+    if (kind == NK_WIRE) { r_re = blk_col(o, 0); r_im = r_re + 32; }
+    else if (kind == NK_WIRE2D) { r_re = ((o >> 5) << 7) + 64 * mat + (o & 31); r_im = r_re + 32; }
+    else r_re = o;
+    float sr = 0.f, si = 0.f, br = 0.f, bi = 0.f;
+    if (i < Kin) {
+      if (cplx) {
+        const int c_re = blk_col(i, 0), c_im = c_re + 32;
+        const size_t a = (size_t)r_re * Pn + c_re, b = (size_t)r_im * Pn + c_im, c = (size_t)r_im * Pn + c_re,
+                     d = (size_t)r_re * Pn + c_im;
+#pragma unroll 4
+        for (int sp = q; sp < S; sp += 4) {
+          const float* m = slab + sp * sstride;
+          sr += m[a] + m[b];
+          si += m[c] - m[d];
+        }
       } else {
-        r_re = ((o >> 5) << 7) + 64 * mat + (o & 31);
-        r_im = r_re + 32;
+        const size_t a = (size_t)o * Pn + i;
+#pragma unroll 4
+        for (int sp = q; sp < S; sp += 4) sr += slab[sp * sstride + a];
       }
+    }
+    if (tx == 0 && blockIdx.x == 0)
+      for (int sp = q; sp < S; sp += 4) {
+        br += bslab[(size_t)sp * Pm + r_re];
+        if (cplx) bi += bslab[(size_t)sp * Pm + r_im];
+      }
+    red[0][q][tx] = sr; red[1][q][tx] = si; red[2][q][tx] = br; red[3][q][tx] = bi;
+    __syncthreads();
+    if (q == 0) {
       float* gWm = mat == 0 ? gW : gV;
       float* gbm = mat == 0 ? gb : gc;
+      const float wr = (red[0][0][tx] + red[0][1][tx]) + (red[0][2][tx] + red[0][3][tx]);
+      const float wi = (red[1][0][tx] + red[1][1][tx]) + (red[1][2][tx] + red[1][3][tx]);
       if (i < Kin) {
-        const int c_re = blk_col(i, 0), c_im = c_re + 32;
-        float sr = 0.f, si = 0.f;
-        for (int s = 0; s < S; ++s) {
-          const float* m = slab + s * sstride;
-          sr += m[(size_t)r_re * Pn + c_re] + m[(size_t)r_im * Pn + c_im];
-          si += m[(size_t)r_im * Pn + c_re] - m[(size_t)r_re * Pn + c_im];
+        if (cplx) {
+          gWm[((size_t)o * Kin + i) * 2] = wr;
+          gWm[((size_t)o * Kin + i) * 2 + 1] = wi;
+        } else {
+          gWm[(size_t)o * Kin + i] = wr;
         }
-        gWm[((size_t)o * Kin + i) * 2] = sr;
-        gWm[((size_t)o * Kin + i) * 2 + 1] = si;
       }
-      if (i == 0) {
-        float br = 0.f, bi = 0.f;
-        for (int s = 0; s < S; ++s) {
-          br += bslab[(size_t)s * Pm + r_re];
-          bi += bslab[(size_t)s * Pm + r_im];
-        }
-        gbm[2 * o] = br;
-        gbm[2 * o + 1] = bi;
+      if (tx == 0 && blockIdx.x == 0) {
+        const float b0 = (red[2][0][0] + red[2][1][0]) + (red[2][2][0] + red[2][3][0]);
+        const float b1 = (red[3][0][0] + red[3][1][0]) + (red[3][2][0] + red[3][3][0]);
+        if (cplx) { gbm[2 * o] = b0; gbm[2 * o + 1] = b1; }
+        else gbm[o] = b0;
       }
     }
-  } else {
-    if (i < Kin) {
-      float sr = 0.f;
-      for (int s = 0; s < S; ++s) sr += slab[s * sstride + (size_t)o * Pn + i];
-      gW[(size_t)o * Kin + i] = sr;
-    }
-    if (i == 0) {
-      float br = 0.f;
-      for (int s = 0; s < S; ++s) br += bslab[(size_t)s * Pm + o];
-      gb[o] = br;
-    }
+    __syncthreads();
   }
 }
 
@@ -697,7 +709,7 @@ hipError_t launch_wgrad_reduce(hipStream_t s, int kind, const float* slab, const
                                int S, int K, int Kin, int Pm, int Pn, float* gW, float* gb,
                                float* gV, float* gc) {
   dim3 grid(cdiv(Kin, 64), (unsigned)K);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, grid, dim3(64), 0, s, kind, slab, bslab, S, K, Kin, Pm,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, grid, dim3(256), 0, s, kind, slab, bslab, S, K, Kin, Pm,
                      Pn, gW, gb, gV, gc);
   return hipGetLastError();
 }
