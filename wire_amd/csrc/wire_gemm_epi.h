@@ -144,6 +144,146 @@ WIRE_DEVINL void gemm_epilogue(f32x16 (&acc)[MT][WN], const GemmEpiParams& ep, c
       return;
     }
   }
+  // ---- lean forms of the real-valued epilogues (siren / gauss / relu) and of the 2-D Gabor: full tiles, uniform
+  // base pointers + 32-bit byte offsets (no 64-bit multiply per element, no row test), loads of 8 rows in flight.
+  // The short GEMMs of these nets (K = 256 real: 16 stages per tile) spend as long in the epilogue as in the main
+  // loop when every element pays a dependent load -> store chain (profiles/r02_siren_kernel_stats.csv).
+  if constexpr (LEAN && (EPI == EPI_SIREN_FWD || EPI == EPI_GAUSS_FWD || EPI == EPI_RELU_FWD)) {
+    if (m_w + MT * 32 <= M && !ep.wide && n_w + WN * 32 <= ep.kvalid) {
+      constexpr int ACT = EPI - EPI_SIREN_FWD;
+      char* __restrict__ lin_b = reinterpret_cast<char*>(ep.o0);
+      char* __restrict__ out_b = reinterpret_cast<char*>(ep.o1);
+      const unsigned ldb4 = (unsigned)ep.ld0 * 4u;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int col = n_w + 32 * j + l31;
+        const float bb = ep.bias[col];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const unsigned off0 = (unsigned)(m_w + 32 * i + 4 * h) * ldb4 + (unsigned)col * 4u;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned off = off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * ldb4;
+            const float lin = acc[i][j][r] + bb;
+            if (lin_b) *reinterpret_cast<float*>(lin_b + off) = lin;
+            *reinterpret_cast<float*>(out_b + off) = real_act_fwd_lean<ACT>(lin, ep.omega, ep.scale);
+          }
+        }
+      }
+      return;
+    }
+  }
+  if constexpr (LEAN && (EPI == EPI_SIREN_BWD || EPI == EPI_GAUSS_BWD || EPI == EPI_RELU_BWD)) {
+    if (m_w + MT * 32 <= M && !ep.wide) {
+      constexpr int ACT = EPI - EPI_SIREN_BWD;
+      const char* __restrict__ lin_b = reinterpret_cast<const char*>(ep.i0);
+      const char* __restrict__ out_b = reinterpret_cast<const char*>(ep.i1);
+      char* __restrict__ gl_b = reinterpret_cast<char*>(ep.o0);
+      const unsigned ldb4 = (unsigned)ep.ld0 * 4u;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int col = n_w + 32 * j + l31;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const unsigned off0 = (unsigned)(m_w + 32 * i + 4 * h) * ldb4 + (unsigned)col * 4u;
+#pragma unroll
+          for (int rb0 = 0; rb0 < 16; rb0 += 8) {
+            float lv[8], ov[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int r = rb0 + q;
+              const unsigned off = off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * ldb4;
+              lv[q] = *reinterpret_cast<const float*>(lin_b + off);
+              ov[q] = (ACT == ACT_GAUSS) ? *reinterpret_cast<const float*>(out_b + off) : 0.f;   // only gauss needs out
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int r = rb0 + q;
+              const unsigned off = off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * ldb4;
+              *reinterpret_cast<float*>(gl_b + off) = real_act_bwd_lean<ACT>(acc[i][j][r], lv[q], ov[q], ep.omega, ep.scale);
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
+  if constexpr (LEAN && EPI == EPI_GABOR2D_FWD) {
+    static_assert(EPI != EPI_GABOR2D_FWD || WN == 4, "2-D Gabor needs a 128-column wave tile");
+    if (m_w + MT * 32 <= M && !ep.wide && ((n_w >> 7) << 5) + 32 <= ep.kvalid) {
+      const int c0 = n_w + l31, grp = n_w >> 7, oc_re = (grp << 6) + l31;
+      const float b_u = ep.bias[c0], b_v = ep.bias[c0 + 32], b_p = ep.bias[c0 + 64], b_q = ep.bias[c0 + 96];
+      char* __restrict__ L_b = reinterpret_cast<char*>(ep.o0);
+      char* __restrict__ O_b = reinterpret_cast<char*>(ep.o1);
+      const unsigned ld0b = (unsigned)ep.ld0 * 4u, ld1b = (unsigned)ep.ld1 * 4u;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const unsigned row0 = (unsigned)(m_w + 32 * i + 4 * h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned row = row0 + (unsigned)((r & 3) + 8 * (r >> 2));
+          const float u = acc[i][0][r] + b_u, v = acc[i][1][r] + b_v;
+          const float pp = acc[i][2][r] + b_p, qq = acc[i][3][r] + b_q;
+          float o_re, o_im;
+          gabor2d_fwd_lean(u, v, pp, qq, ep.omega, ep.scale, o_re, o_im);
+          if (L_b) {
+            float* Lp = reinterpret_cast<float*>(L_b + row * ld0b + (unsigned)c0 * 4u);
+            Lp[0] = u; Lp[32] = v; Lp[64] = pp; Lp[96] = qq;
+          }
+          float* Op = reinterpret_cast<float*>(O_b + row * ld1b + (unsigned)oc_re * 4u);
+          Op[0] = o_re; Op[32] = o_im;
+        }
+      }
+      return;
+    }
+  }
+  if constexpr (LEAN && EPI == EPI_GABOR2D_BWD) {
+    if (m_w + MT * 32 <= M && !ep.wide) {
+      const float m2s2 = -2.f * ep.scale * ep.scale, w0 = ep.omega;
+      const char* __restrict__ L_b = reinterpret_cast<const char*>(ep.i0);
+      const char* __restrict__ O_b = reinterpret_cast<const char*>(ep.i1);
+      char* __restrict__ G_b = reinterpret_cast<char*>(ep.o0);
+      const unsigned ld0b = (unsigned)ep.ld0 * 4u, ld1b = (unsigned)ep.ld1 * 4u;
+#pragma unroll
+      for (int jp = 0; jp < WN; jp += 2) {
+        const int c_re = n_w + 32 * jp + l31;
+        const int grp = c_re >> 6;
+        const unsigned lc4 = (unsigned)((grp << 7) + l31) * 4u, oc4 = (unsigned)c_re * 4u;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const unsigned row0 = (unsigned)(m_w + 32 * i + 4 * h);
+#pragma unroll
+          for (int rb0 = 0; rb0 < 16; rb0 += 4) {
+            float u[4], v[4], pp[4], qq[4], pr[4], pi[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int r = rb0 + q;
+              const unsigned row = row0 + (unsigned)((r & 3) + 8 * (r >> 2));
+              const float* Lp = reinterpret_cast<const float*>(L_b + row * ld0b + lc4);
+              const float* Op = reinterpret_cast<const float*>(O_b + row * ld1b + oc4);
+              u[q] = Lp[0]; v[q] = Lp[32]; pp[q] = Lp[64]; qq[q] = Lp[96];
+              pr[q] = Op[0]; pi[q] = Op[32];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int r = rb0 + q;
+              const unsigned row = row0 + (unsigned)((r & 3) + 8 * (r >> 2));
+              const float gr = acc[i][jp][r], gi = acc[i][jp + 1][r];
+              const float c_r = __builtin_fmaf(pr[q], gr, pi[q] * gi);
+              const float c_i = __builtin_fmaf(pr[q], gi, -(pi[q] * gr));
+              const float t = m2s2 * c_r;
+              float* Gp = reinterpret_cast<float*>(G_b + row * ld0b + lc4);
+              Gp[0] = __builtin_fmaf(t, u[q], w0 * c_i);
+              Gp[32] = __builtin_fmaf(t, v[q], -(w0 * c_r));
+              Gp[64] = t * pp[q];
+              Gp[96] = t * qq[q];
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
   if constexpr (EPI == EPI_STORE) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)

@@ -333,9 +333,11 @@ static int g_x3_tn_tall = x3_env("WIRE_X3_TN_TALL", 0);   // 256 x 128 tiles in 
 // 256-row tiles (4 x 2 MFMA tiles per wave) for the Gabor epilogues of large batches: fewer weight bytes
 // per MFMA through the 64 B/clk L1 path (tools/mfma_bf16_probe.hip), 7-9 % faster at N = 262144
 static int g_x3_tall = x3_env("WIRE_X3_TALL", 1);
+static int g_x3_tall_real = x3_env("WIRE_X3_TALL_REAL", 0);   // the same for siren / gauss / relu (A/B switch)
 int gemmx3_tune_set(const char* key, int value) {
   if (!strcmp(key, "x3_tall") && (value == 0 || value == 1)) { g_x3_tall = value; return 0; }
   if (!strcmp(key, "x3_tn_tall") && (value == 0 || value == 1)) { g_x3_tn_tall = value; return 0; }
+  if (!strcmp(key, "x3_tall_real") && (value == 0 || value == 1)) { g_x3_tall_real = value; return 0; }
   return gemmx3g_tune_set(key, value);
 }
 
@@ -346,9 +348,22 @@ hipError_t launch_gemmx3_nt(hipStream_t s, int epi, const float* A, int lda, con
   if ((Nc & 63) || (Kd & 31) || (lda & 3) || M > 0x7fffff00LL) return hipErrorInvalidValue;
   // the lean Gabor epilogues share one 32-bit byte offset between their buffers
   GemmEpiParams ep = ep_in;
-  if ((epi == EPI_GABOR_FWD || epi == EPI_GABOR_BWD) && ep.ld0 != ep.ld1) ep.wide = 1;
+  if ((epi == EPI_GABOR_FWD || epi == EPI_GABOR_BWD || (epi >= EPI_SIREN_FWD && epi <= EPI_RELU_BWD)) &&
+      ep.ld0 != ep.ld1)
+    ep.wide = 1;
   if ((double)M * (double)(ep.ld1 > ep.ld0 ? ep.ld1 : ep.ld0) * 4.0 >= 4294967296.0) ep.wide = 1;
   // (256-row tiles for wire2d and the real nets were measured 5 % SLOWER on their steps: they stay on 128 rows)
+  if (g_x3_tall_real && M >= 4096) {
+    switch (epi) {
+      case EPI_SIREN_FWD: return launchx3_nt_t<EPI_SIREN_FWD, 4, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+      case EPI_GAUSS_FWD: return launchx3_nt_t<EPI_GAUSS_FWD, 4, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+      case EPI_RELU_FWD: return launchx3_nt_t<EPI_RELU_FWD, 4, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+      case EPI_SIREN_BWD: return launchx3_nt_t<EPI_SIREN_BWD, 4, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+      case EPI_GAUSS_BWD: return launchx3_nt_t<EPI_GAUSS_BWD, 4, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+      case EPI_RELU_BWD: return launchx3_nt_t<EPI_RELU_BWD, 4, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);
+      default: break;
+    }
+  }
   if (g_x3_tall && M >= 4096) {
     switch (epi) {
       case EPI_STORE: return launchx3_nt_t<EPI_STORE, 4, 2>(s, A, lda, Bx3, M, Nc, Kd, ep);

@@ -293,7 +293,9 @@ hipError_t launch_gemmx3g_nt(hipStream_t s, int epi, const float* A, int lda, co
   if (M <= 0) return hipSuccess;
   if ((Nc & 63) || (Kd & 31) || (lda & 3) || M > 0x7fffff00LL) return hipErrorInvalidValue;
   GemmEpiParams ep = ep_in;
-  if ((epi == EPI_GABOR_FWD || epi == EPI_GABOR_BWD) && ep.ld0 != ep.ld1) ep.wide = 1;
+  if ((epi == EPI_GABOR_FWD || epi == EPI_GABOR_BWD || (epi >= EPI_SIREN_FWD && epi <= EPI_RELU_BWD)) &&
+      ep.ld0 != ep.ld1)
+    ep.wide = 1;
   if ((double)M * (double)(ep.ld1 > ep.ld0 ? ep.ld1 : ep.ld0) * 4.0 >= 4294967296.0) ep.wide = 1;
   ep.stagger = g_x3_stagger; ep.stagger_lo = g_x3_stagger_lo; ep.stagger_hi = g_x3_stagger_hi;
   // mode 3 (probe): the mode-1 tile with 4 buffers = 112 KB of LDS -> ONE workgroup per CU, one wave per SIMD
