@@ -635,7 +635,13 @@ int gemmx3_tn_splits(int64_t n, int Pm, int Pn, int max_splits) {
   if (s > by_rows) s = (int)by_rows;
   if (s > max_splits) s = max_splits;
   if (s < 1) s = 1;
-  return s;
+  // what the launcher will actually use once the split length is rounded to whole 32-row double stages: callers that
+  // pass this count get no empty split (and no memset of unused slabs)
+  if (n < 1) return s;
+  long long chunk = (n + s - 1) / s;
+  chunk = (chunk + 2 * X3_TK - 1) / (2 * X3_TK) * (2 * X3_TK);
+  s = (int)((n + chunk - 1) / chunk);
+  return s < 1 ? 1 : s;
 }
 
 hipError_t launch_gemmx3_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n,

@@ -269,50 +269,65 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(
     const float m2s2 = -2.f * scale * scale;
     const int Pl = (KIND == NK_WIRE2D) ? 2 * P : P;
     const int lc = (KIND == NK_WIRE2D) ? (((f >> 5) << 7) + (f & 31)) : c0;
-#pragma unroll 4
-    for (int r = 0; r < nr; ++r) {
-      const long long row = r0 + r;
-      float gr = 0.f, gi = 0.f;
+    // rows in batches of 8: every load of a batch is issued before its first use (a per-row load -> use -> store
+    // chain left this kernel at 2 TB/s; profiles/r02_siren_kernel_stats.csv)
+    constexpr int RB = 8;
+    for (int rb = 0; rb < nr; rb += RB) {
+      float pr[RB], pi[RB], l0[RB], l1[RB], l2[RB], l3[RB];
 #pragma unroll
-      for (int o = 0; o < MAXO; ++o)
-        if (o < O) {
-          const float g = sgy[r * O + o];
-          gr = __builtin_fmaf(g, w0[o], gr);
-          if (cplx) gi = __builtin_fmaf(g, w1[o], gi);
+      for (int q = 0; q < RB; ++q) {
+        const int r = rb + q < nr ? rb + q : nr - 1;       // clamped: tail rows re-read the last one
+        const long long row = r0 + r;
+        pr[q] = out[row * P + c0];
+        pi[q] = cplx ? out[row * P + c0 + 32] : 0.f;
+        l0[q] = l1[q] = l2[q] = l3[q] = 0.f;
+        if (!RAW) {
+          if (KIND == NK_WIRE2D) {
+            const float* L = lin + row * Pl + lc;
+            l0[q] = L[0]; l1[q] = L[32]; l2[q] = L[64]; l3[q] = L[96];
+          } else {
+            l0[q] = lin[row * P + c0];
+            if (KIND == NK_WIRE) l1[q] = lin[row * P + c0 + 32];
+          }
         }
-      const float pr = out[row * P + c0];
-      const float pi = cplx ? out[row * P + c0 + 32] : 0.f;
+      }
 #pragma unroll
-      for (int o = 0; o < MAXO; ++o)
-        if (o < O) {
-          const float g = sgy[r * O + o];
-          a0[o] = __builtin_fmaf(g, pr, a0[o]);
-          if (cplx) a1[o] = __builtin_fmaf(g, pi, a1[o]);
+      for (int q = 0; q < RB; ++q) {
+        const int r = rb + q;
+        if (r < nr) {
+          const long long row = r0 + r;
+          float gr = 0.f, gi = 0.f;
+#pragma unroll
+          for (int o = 0; o < MAXO; ++o)
+            if (o < O) {
+              const float g = sgy[r * O + o];
+              gr = __builtin_fmaf(g, w0[o], gr);
+              if (cplx) gi = __builtin_fmaf(g, w1[o], gi);
+              a0[o] = __builtin_fmaf(g, pr[q], a0[o]);
+              if (cplx) a1[o] = __builtin_fmaf(g, pi[q], a1[o]);
+            }
+          if (RAW) {
+            g_lin[row * P + c0] = gr;
+            if (cplx) g_lin[row * P + c0 + 32] = gi;
+          } else if (KIND == NK_WIRE) {
+            float gl_re, gl_im;
+            gabor_bwd(gr, gi, l0[q], l1[q], pr[q], pi[q], omega, m2s2, gl_re, gl_im);
+            g_lin[row * P + c0] = gl_re;
+            g_lin[row * P + c0 + 32] = gl_im;
+          } else if (KIND == NK_WIRE2D) {
+            const float c_r = __builtin_fmaf(pr[q], gr, pi[q] * gi);
+            const float c_i = __builtin_fmaf(pr[q], gi, -(pi[q] * gr));
+            const float t = m2s2 * c_r;
+            float* Gp = g_lin + row * Pl + lc;
+            Gp[0] = __builtin_fmaf(t, l0[q], omega * c_i);
+            Gp[32] = __builtin_fmaf(t, l1[q], -(omega * c_r));
+            Gp[64] = t * l2[q];
+            Gp[96] = t * l3[q];
+          } else {
+            constexpr int ACT = (KIND - NK_SIREN) < 0 ? 0 : (KIND - NK_SIREN);
+            g_lin[row * P + c0] = real_act_bwd<ACT>(gr, l0[q], pr[q], omega, scale);
+          }
         }
-      if (RAW) {
-        g_lin[row * P + c0] = gr;
-        if (cplx) g_lin[row * P + c0 + 32] = gi;
-      } else if (KIND == NK_WIRE) {
-        const float u = lin[row * P + c0], v = lin[row * P + c0 + 32];
-        float gl_re, gl_im;
-        gabor_bwd(gr, gi, u, v, pr, pi, omega, m2s2, gl_re, gl_im);
-        g_lin[row * P + c0] = gl_re;
-        g_lin[row * P + c0 + 32] = gl_im;
-      } else if (KIND == NK_WIRE2D) {
-        const float* L = lin + row * Pl + lc;
-        const float u = L[0], v = L[32], p = L[64], q = L[96];
-        const float c_r = __builtin_fmaf(pr, gr, pi * gi);
-        const float c_i = __builtin_fmaf(pr, gi, -(pi * gr));
-        const float t = m2s2 * c_r;
-        float* Gp = g_lin + row * Pl + lc;
-        Gp[0] = __builtin_fmaf(t, u, omega * c_i);
-        Gp[32] = __builtin_fmaf(t, v, -(omega * c_r));
-        Gp[64] = t * p;
-        Gp[96] = t * q;
-      } else {
-        constexpr int ACT = (KIND - NK_SIREN) < 0 ? 0 : (KIND - NK_SIREN);
-        const float l = lin[row * P + c0];
-        g_lin[row * P + c0] = real_act_bwd<ACT>(gr, l, pr, omega, scale);
       }
     }
     float* pw = part_w + (size_t)blockIdx.x * O * P;
