@@ -253,6 +253,12 @@ int wire_gabor2d_bwd(void* stream, const void* g_act, const void* x, const void*
                      int in_features, int out_features, int is_first, void* g_x, void* g_W, void* g_b,
                      void* g_V, void* g_c, void* ws, int64_t ws_bytes);
 
+/* trainable omega_0 / scale_0 of ComplexGaborLayer2D (modules/wire2d.py:42-43 with trainable=True):
+ * out2 (device, 2 floats) = { dL/d omega_0, dL/d scale_0 }; operands and workspace as wire_gabor2d_bwd. */
+int wire_gabor2d_hparam_grad(void* stream, const void* g_act, const void* x, const void* W, const void* b,
+                             const void* V, const void* c, float omega0, float scale0, int64_t n, int in_features,
+                             int out_features, int is_first, float* out2, void* ws, int64_t ws_bytes);
+
 /* ---- layout helpers ---------------------------------------------------- */
 int wire_blocked_width(int K);   /* P = roundup(2K, 64) */
 int wire_c64_to_blocked(void* stream, const void* src, int64_t n, int K, float* dst);

@@ -302,6 +302,45 @@ def misc2():
     print("misc2: iou =", rec["iou_val"], "trainable g_omega (hid) =", rec["tr_hid_g_omega"], rec["tr_hid_g_omega64"])
 
 
+def misc3():
+    """ComplexGaborLayer2D(trainable=True) (modules/wire2d.py:21-67): gradients of omega_0 / scale_0 and of both
+    Linears, hidden and first layer, fp32 and fp64."""
+    rec = {}
+    rng = np.random.default_rng(13)
+    for tag, is_first, fin in (("hid", False, 20), ("first", True, 2)):
+        torch.manual_seed(41)
+        layer = wire2d.ComplexGaborLayer2D(fin, 36, is_first=is_first, omega0=6.0, sigma0=3.0, trainable=True)
+        n = 256
+        if is_first:
+            x = torch.tensor(rng.uniform(-1, 1, (n, fin)).astype(np.float32))
+        else:
+            x = torch.tensor((0.3 * (rng.standard_normal((n, fin)) + 1j * rng.standard_normal((n, fin)))).astype(np.complex64))
+        g = torch.tensor((rng.standard_normal((n, 36)) + 1j * rng.standard_normal((n, 36))).astype(np.complex64))
+        for dbl in (False, True):
+            lay = wire2d.ComplexGaborLayer2D(fin, 36, is_first=is_first, omega0=6.0, sigma0=3.0, trainable=True)
+            lay.load_state_dict(layer.state_dict())
+            xx, gg = x.clone(), g.clone()
+            if dbl:
+                to_double(lay)
+                xx = xx.to(torch.double if is_first else torch.cdouble)
+                gg = gg.to(torch.cdouble)
+            xx.requires_grad_(not is_first)
+            out = lay(xx)
+            (out.real * gg.real + out.imag * gg.imag).sum().backward()
+            sfx = "64" if dbl else ""
+            rec[f"tr2d_{tag}_out{sfx}"] = out.detach().numpy()
+            for nm, prm in (("g_omega", lay.omega_0), ("g_scale", lay.scale_0), ("g_W", lay.linear.weight),
+                            ("g_b", lay.linear.bias), ("g_V", lay.scale_orth.weight), ("g_c", lay.scale_orth.bias)):
+                rec[f"tr2d_{tag}_{nm}{sfx}"] = prm.grad.numpy()
+            if not is_first:
+                rec[f"tr2d_{tag}_g_x{sfx}"] = xx.grad.numpy()
+        rec[f"tr2d_{tag}_x"], rec[f"tr2d_{tag}_g"] = x.numpy(), g.numpy()
+        for k, v in layer.state_dict().items():
+            rec[f"tr2d_{tag}_p:{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "misc3.npz"), **rec)
+    print("misc3: g_omega", rec["tr2d_hid_g_omega"], rec["tr2d_hid_g_omega64"], "g_scale", rec["tr2d_hid_g_scale64"])
+
+
 def ct_pair():
     """The reference holds one input/output pair of its CT forward operator (lin_inverse.radon, which needs kornia):
     the phantom ``gt`` and its ``sinogram`` over np.linspace(0, 180, 100) degrees, saved by wire_ct.py:160-163 into
@@ -318,6 +357,9 @@ def ct_pair():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "misc2":
         misc2()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "misc3":
+        misc3()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ct_pair":
         ct_pair()
@@ -350,4 +392,5 @@ if __name__ == "__main__":
              pos_encode=True, sidelength=512)
     misc()
     misc2()
+    misc3()
     ct_pair()

@@ -305,3 +305,64 @@ def test_second_backward_with_retain_graph():
     loss.backward()
     for a, p in zip(g1, [p for p in model.parameters() if p.grad is not None]):
         assert torch.allclose(p.grad, 2 * a, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("tag,is_first", [("hid", False), ("first", True)])
+def test_trainable_omega_scale_gradients_2d(tag, is_first):
+    """ComplexGaborLayer2D(trainable=True) (modules/wire2d.py:42-43): forward and every gradient against the
+    reference's fp64 autograd (tests/golden/misc3.npz)."""
+    from wire_amd.modules.wire2d import ComplexGaborLayer2D
+    m3 = load_golden("misc3")
+    fin = m3[f"tr2d_{tag}_x"].shape[1]
+    layer = ComplexGaborLayer2D(fin, 36, is_first=is_first, omega0=6.0, sigma0=3.0, trainable=True)
+    layer.load_state_dict({k.split(":", 1)[1]: torch.tensor(v) for k, v in m3.items() if k.startswith(f"tr2d_{tag}_p:")})
+    layer = layer.cuda()
+    x = torch.tensor(m3[f"tr2d_{tag}_x"], device="cuda", requires_grad=not is_first)
+    out = layer(x)
+    out.backward(torch.tensor(m3[f"tr2d_{tag}_g"], device="cuda"))
+    torch.cuda.synchronize()
+    assert relmax(out.detach().cpu().numpy(), m3[f"tr2d_{tag}_out64"]) <= 1e-5
+    got = {"g_omega": layer.omega_0.grad, "g_scale": layer.scale_0.grad, "g_W": layer.linear.weight.grad,
+           "g_b": layer.linear.bias.grad, "g_V": layer.scale_orth.weight.grad, "g_c": layer.scale_orth.bias.grad}
+    if not is_first:
+        got["g_x"] = x.grad
+    for k, v in got.items():
+        ref64, ref32 = m3[f"tr2d_{tag}_{k}64"], m3[f"tr2d_{tag}_{k}"]
+        if k in ("g_omega", "g_scale"):
+            scale = max(abs(float(ref64[0])), 1.0)
+            assert abs(float(v.item()) - float(ref64[0])) <= 2 * abs(float(ref32[0]) - float(ref64[0])) + 2e-5 * scale, k
+        else:
+            within_ref(relmax(v.cpu().numpy(), ref64), relmax(ref32, ref64), f"trainable2d {tag} {k}", floor=2e-6)
+
+
+def test_mesh_export_occupancy_query():
+    """The dense query of export_mesh (modules/volutils.py:113-133: batches of coordinates -> torch.sigmoid(model(c)) ->
+    the occupancy cube handed to marching cubes), through the drop-in module and through FusedTrainer.render."""
+    from wire_amd.modules import models, utils, volutils
+    from wire_amd.trainer import FusedTrainer
+    torch.manual_seed(0)
+    model = models.get_INR(nonlin="wire", in_features=3, out_features=1, hidden_features=48, hidden_layers=2,
+                           first_omega_0=10.0, hidden_omega_0=10.0, scale=8.0).cuda()
+    res = 11
+    coords = utils.get_coords(res, res, res)
+    cube = volutils.query_occupancy(coords, res, model, batchsize=500)
+    assert cube.shape == (res, res, res) and cube.dtype == np.float32
+    P64 = wo.cast_params({k: v.detach().cpu().numpy() for k, v in model.state_dict().items()
+                          if "omega_0" not in k and "scale_0" not in k}, True)
+    y64 = wo.wire_forward(P64, coords.numpy().astype(np.float64), 2, 10.0, 10.0, 8.0)
+    ref = 1.0 / (1.0 + np.exp(-y64))
+    assert np.abs(cube.reshape(-1, 1) - ref).max() <= 2e-5
+    tr = FusedTrainer(model, (res, res, res), torch.zeros(res ** 3, 1), coords_style="numpy")
+    cube2 = tr.render(tile=400, sigmoid=True).cpu().numpy()
+    assert np.abs(cube2 - ref).max() <= 2e-5
+
+
+def test_index_range_check_is_opt_in(monkeypatch):
+    from wire_amd.modules import models
+    from wire_amd.trainer import FusedTrainer
+    model = models.get_INR(nonlin="wire", in_features=2, out_features=3, hidden_features=32, hidden_layers=1).cuda()
+    tr = FusedTrainer(model, (8, 8), torch.zeros(64, 3))
+    monkeypatch.setenv("WIRE_CHECK_INDICES", "1")
+    with pytest.raises(ValueError):
+        tr.step(torch.tensor([0, 5, 64], device="cuda"))           # 64 is outside the 8 x 8 grid
+    tr.step(torch.tensor([0, 5, 63], device="cuda"))

@@ -50,7 +50,21 @@ WIRE_DEVINL void g_split2(float x0, float x1, unsigned& H, unsigned& Mi, unsigne
   L = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
 }
 
+#ifdef WIRE_ABLATE_G16
+// probe only (results wrong): the same flops issued as 16x16x32 MFMAs -- two per 32x32x16, on quarters of the
+// accumulator -- to measure the sustained rate of that shape under this kernel's mix
+typedef float gf32x4 __attribute__((ext_vector_type(4)));
+#define G_MFMA(a, b, c)                                                                                   \
+  do {                                                                                                    \
+    gf32x4 q0_ = {c[0], c[1], c[2], c[3]}, q1_ = {c[4], c[5], c[6], c[7]};                                \
+    q0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q0_, 0, 0, 0);                                    \
+    q1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q1_, 0, 0, 0);                                    \
+    c[0] = q0_[0]; c[1] = q0_[1]; c[2] = q0_[2]; c[3] = q0_[3];                                           \
+    c[4] = q1_[0]; c[5] = q1_[1]; c[6] = q1_[2]; c[7] = q1_[3];                                           \
+  } while (0)
+#else
 #define G_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
 
 // one 1-KiB piece: lane i's 16 bytes land at lds_piece + 16 i
 WIRE_DEVINL void g_dma16(const void* gsrc, unsigned char* lds_piece) {
@@ -298,8 +312,11 @@ hipError_t launch_gemmx3g_nt(hipStream_t s, int epi, const float* A, int lda, co
     ep.wide = 1;
   if ((double)M * (double)(ep.ld1 > ep.ld0 ? ep.ld1 : ep.ld0) * 4.0 >= 4294967296.0) ep.wide = 1;
   ep.stagger = g_x3_stagger; ep.stagger_lo = g_x3_stagger_lo; ep.stagger_hi = g_x3_stagger_hi;
-  // mode 3 (probe): the mode-1 tile with 4 buffers = 112 KB of LDS -> ONE workgroup per CU, one wave per SIMD
+#ifdef WIRE_ABLATE_G
+  // mode 3 (probe, harness build only): the mode-1 tile with 4 buffers = 112 KB of LDS -> ONE workgroup per CU, one
+  // wave per SIMD
   if (g_x3_glds == 3 && epi == EPI_STORE) return launchx3g_t<EPI_STORE, 2, 4, 4, 1, 4>(s, A, lda, Bx3, M, Nc, Kd, ep);
+#endif
 #define X3G_CASE(E)                                                                                  \
   case E:                                                                                            \
     return g_x3_glds == 2 ? launchx3g_t<E, 2, 4, 4, 2, 3>(s, A, lda, Bx3, M, Nc, Kd, ep)             \

@@ -382,11 +382,12 @@ Layer2dWs layer2d_ws(int64_t n, int in, int out) {
 // forward into the workspace (linsy, out blocked); shared by fwd and bwd
 int layer2d_forward_ws(hipStream_t s, const Layer2dWs& w, float* W_, const void* x, const void* Wt, const void* b,
                        const void* Vt, const void* c, float omega0, float scale0, int64_t n, int in, int out,
-                       int is_first) {
+                       int is_first, bool want_lin = false) {
   if (is_first) {
     if (in > 4) return wire_fail_(WIRE_ERR_ARG, "is_first layers support in_features <= 4");
     LCHK(launch_first_fwd(s, NK_WIRE2D, (const float*)x, n, in, (const float*)Wt, (const float*)b,
-                          (const float*)Vt, (const float*)c, out, w.Pout, omega0, scale0, nullptr, W_ + w.out));
+                          (const float*)Vt, (const float*)c, out, w.Pout, omega0, scale0,
+                          want_lin ? W_ + w.linsy : nullptr, W_ + w.out));
     return WIRE_OK;
   }
   const LayerGemm g{wire_family_(WIRE_KIND_WIRE2D)};
@@ -420,6 +421,25 @@ extern "C" int wire_gabor2d_fwd(void* stream, const void* x, const void* W, cons
   if (int rc = layer2d_forward_ws(s, w, W_, x, W, b, V, c, omega0, scale0, n, in_features, out_features, is_first))
     return rc;
   LCHK(launch_blocked_to_c64(s, W_ + w.out, n, out_features, w.Pout, (float*)act_out));
+  return WIRE_OK;
+}
+
+// trainable omega_0 / scale_0 of ComplexGaborLayer2D (modules/wire2d.py:42-43): out2 = {dL/d omega_0, dL/d scale_0}
+extern "C" int wire_gabor2d_hparam_grad(void* stream, const void* g_act, const void* x, const void* W, const void* b,
+                                        const void* V, const void* c, float omega0, float scale0, int64_t n,
+                                        int in_features, int out_features, int is_first, float* out2, void* ws,
+                                        int64_t ws_bytes) {
+  if (n <= 0 || in_features < 1 || out_features < 1 || !g_act || !x || !W || !b || !V || !c || !out2 || !ws)
+    return wire_fail_(WIRE_ERR_ARG, "bad argument to wire_gabor2d_hparam_grad");
+  const Layer2dWs w = layer2d_ws(n, in_features, out_features);
+  if (ws_bytes < w.total * 4) return wire_fail_(WIRE_ERR_SIZE, "layer workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* W_ = (float*)ws;
+  if (int rc = layer2d_forward_ws(s, w, W_, x, W, b, V, c, omega0, scale0, n, in_features, out_features, is_first, true))
+    return rc;
+  LCHK(launch_c64_to_blocked(s, (const float*)g_act, n, out_features, w.Pout, W_ + w.gact));
+  LCHK(launch_gabor2d_hparam_grad(s, W_ + w.gact, W_ + w.linsy, W_ + w.out, n, out_features, w.Pout, is_first, scale0,
+                                  W_ + w.glinsy, out2));
   return WIRE_OK;
 }
 

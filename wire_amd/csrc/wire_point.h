@@ -120,6 +120,8 @@ hipError_t launch_wgrad3m_reduce(hipStream_t s, const float* slab, const float* 
 int hparam_blocks(int64_t n);
 hipError_t launch_gabor_hparam_grad(hipStream_t s, const float* g, const float* lin, const float* out, int64_t n,
                                     int K, int P, int is_first, float scale, float* partial, float* out2);
+hipError_t launch_gabor2d_hparam_grad(hipStream_t s, const float* g, const float* linsy, const float* out, int64_t n,
+                                      int K, int P, int is_first, float scale, float* partial, float* out2);
 
 // ---- best-so-far tracking on the device and the sigmoid of the mesh-export query
 hipError_t launch_track_best(hipStream_t s, const float* metric, float* best, int force, const float* src,

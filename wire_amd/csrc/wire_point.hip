@@ -150,6 +150,10 @@ __global__ void first_fwd_kernel(const float* __restrict__ coords, long long n, 
       gabor2d_fwd(u, 0.f, p, 0.f, omega, scale, o_re, o_im);
       out[row * P + c_re] = valid ? o_re : 0.f;
       out[row * P + c_re + 32] = valid ? o_im : 0.f;
+      if (lin) {                                            // per-layer API only: real (u | p), [n][2 * P / 2]
+        lin[row * (2 * nfeat) + f] = valid ? u : 0.f;
+        lin[row * (2 * nfeat) + nfeat + f] = valid ? p : 0.f;
+      }
     } else {
       constexpr int ACT = KIND - NK_SIREN;
       const float o = real_act_fwd<ACT < 0 ? 0 : ACT>(u, omega, scale);
@@ -1481,7 +1485,61 @@ __global__ __launch_bounds__(256) void gabor_hparam_final_kernel(const float* __
     out2[1] = -2.f * scale * red[1][0];
   }
 }
+// the same for ComplexGaborLayer2D (modules/wire2d.py:56-67): out = exp(j w0 lin) exp(-s0^2 (|lin|^2 + |sy|^2))
+//   d out / d w0 = j lin out,  d out / d s0 = -2 s0 (|lin|^2 + |sy|^2) out.
+// linsy: [n][2P] in 128-column groups (u | v | p | q), or (is_first) real (u | p) [n][2 * P/2].
+__global__ __launch_bounds__(256) void gabor2d_hparam_partial_kernel(const float* __restrict__ g,
+                                                                     const float* __restrict__ linsy,
+                                                                     const float* __restrict__ out, long long n, int K,
+                                                                     int P, int is_first, float* __restrict__ partial) {
+  __shared__ float red[2][256];
+  const long long r0 = (long long)blockIdx.x * HP_ROWS;
+  long long r1 = r0 + HP_ROWS;
+  if (r1 > n) r1 = n;
+  const int Kp = P >> 1;
+  float aw = 0.f, as = 0.f;
+  for (long long row = r0; row < r1; ++row)
+    for (int f = threadIdx.x; f < K; f += 256) {
+      const size_t c = (size_t)row * P + blk_col(f, 0);
+      const float gr = g[c], gi = g[c + 32], pr = out[c], pi = out[c + 32];
+      float u, v = 0.f, pp, qq = 0.f;
+      if (is_first) {
+        u = linsy[(size_t)row * (2 * Kp) + f];
+        pp = linsy[(size_t)row * (2 * Kp) + Kp + f];
+      } else {
+        const float* L = linsy + (size_t)row * (2 * P) + ((f >> 5) << 7) + (f & 31);
+        u = L[0]; v = L[32]; pp = L[64]; qq = L[96];
+      }
+      const float c_r = __builtin_fmaf(pr, gr, pi * gi);
+      const float c_i = __builtin_fmaf(pr, gi, -(pi * gr));
+      aw += __builtin_fmaf(u, c_i, -(v * c_r));
+      as += (__builtin_fmaf(u, u, v * v) + __builtin_fmaf(pp, pp, qq * qq)) * c_r;
+    }
+  red[0][threadIdx.x] = aw;
+  red[1][threadIdx.x] = as;
+  __syncthreads();
+  for (int sft = 128; sft >= 1; sft >>= 1) {
+    if ((int)threadIdx.x < sft) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + sft];
+      red[1][threadIdx.x] += red[1][threadIdx.x + sft];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = red[0][0];
+    partial[gridDim.x + blockIdx.x] = red[1][0];
+  }
+}
 int hparam_blocks(int64_t n) { return (int)((n + HP_ROWS - 1) / HP_ROWS); }
+hipError_t launch_gabor2d_hparam_grad(hipStream_t s, const float* g, const float* linsy, const float* out, int64_t n,
+                                      int K, int P, int is_first, float scale, float* partial, float* out2) {
+  if (n <= 0) return hipErrorInvalidValue;
+  const int nblk = (int)((n + HP_ROWS - 1) / HP_ROWS);
+  hipLaunchKernelGGL(gabor2d_hparam_partial_kernel, dim3((unsigned)nblk), dim3(256), 0, s, g, linsy, out, (long long)n,
+                     K, P, is_first, partial);
+  hipLaunchKernelGGL(gabor_hparam_final_kernel, dim3(1), dim3(256), 0, s, partial, nblk, scale, out2);
+  return hipGetLastError();
+}
 hipError_t launch_gabor_hparam_grad(hipStream_t s, const float* g, const float* lin, const float* out, int64_t n,
                                     int K, int P, int is_first, float scale, float* partial, float* out2) {
   if (n <= 0) return hipErrorInvalidValue;

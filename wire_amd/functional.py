@@ -226,6 +226,51 @@ def gabor2d_layer(x, W, b, V, c, omega0: float, scale0: float, is_first: bool):
     return _Gabor2DLayerFunction.apply(x, W, b, V, c, float(omega0), float(scale0), bool(is_first))
 
 
+class _Gabor2DLayerTrainableFunction(torch.autograd.Function):
+    """ComplexGaborLayer2D with trainable omega_0 / scale_0 (modules/wire2d.py:42-43, trainable=True):
+    wire_gabor2d_fwd / wire_gabor2d_bwd + wire_gabor2d_hparam_grad."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, V, c, omega, scale, is_first: bool):
+        omega0, scale0 = float(omega.detach().reshape(-1)[0]), float(scale.detach().reshape(-1)[0])
+        with torch.no_grad():
+            act = _Gabor2DLayerFunction.apply(x.detach(), W.detach(), b.detach(), V.detach(), c.detach(), omega0,
+                                              scale0, is_first)
+        in_f = W.shape[1]
+        xin = x.detach().to(torch.float32 if is_first else torch.complex64).contiguous()
+        ctx.save_for_backward(xin, _native(W), _native(b), _native(V), _native(c))
+        ctx.cfg = (omega0, scale0, is_first, xin.numel() // in_f, in_f, W.shape[0], tuple(x.shape), omega.shape,
+                   scale.shape)
+        return act
+
+    @staticmethod
+    def backward(ctx, g_act):
+        L = _lib.lib()
+        xin, Wn, bn, Vn, cn = ctx.saved_tensors
+        omega0, scale0, is_first, n, in_f, out_f, xshape, oshape, sshape = ctx.cfg
+        dev = g_act.device
+        g = g_act.detach().to(torch.complex64).contiguous()
+        ws_bytes = _lib.check(L.wire_layer2d_ws_bytes(n, in_f, out_f), "wire_layer2d_ws_bytes")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        gW, gb, gV, gc = (torch.empty_like(t) for t in (Wn, bn, Vn, cn))
+        gx = None if is_first else torch.empty(xshape, dtype=torch.complex64, device=dev)
+        stream = _stream_ptr(dev)
+        _lib.check(L.wire_gabor2d_bwd(stream, g.data_ptr(), xin.data_ptr(), Wn.data_ptr(), bn.data_ptr(), Vn.data_ptr(),
+                                      cn.data_ptr(), omega0, scale0, n, in_f, out_f, int(is_first),
+                                      None if gx is None else gx.data_ptr(), gW.data_ptr(), gb.data_ptr(),
+                                      gV.data_ptr(), gc.data_ptr(), ws.data_ptr(), ws_bytes), "wire_gabor2d_bwd")
+        hp = torch.empty(2, dtype=torch.float32, device=dev)
+        _lib.check(L.wire_gabor2d_hparam_grad(stream, g.data_ptr(), xin.data_ptr(), Wn.data_ptr(), bn.data_ptr(),
+                                              Vn.data_ptr(), cn.data_ptr(), omega0, scale0, n, in_f, out_f,
+                                              int(is_first), hp.data_ptr(), ws.data_ptr(), ws_bytes),
+                   "wire_gabor2d_hparam_grad")
+        return gx, gW, gb, gV, gc, hp[0].reshape(oshape), hp[1].reshape(sshape), None
+
+
+def gabor2d_layer_trainable(x, W, b, V, c, omega: torch.Tensor, scale: torch.Tensor, is_first: bool):
+    return _Gabor2DLayerTrainableFunction.apply(x, W, b, V, c, omega, scale, bool(is_first))
+
+
 class _FinalLinearFunction(torch.autograd.Function):
     """Re(z W_f^T + b_f): wire_final_fwd / wire_final_bwd."""
 

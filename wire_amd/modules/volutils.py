@@ -56,3 +56,26 @@ def get_IoU_batch(preds, gt, thres=None, maxpoints=int(50e6)):
         inter.append(i)
         union.append(u)
     return sum(inter) / sum(union)
+
+
+def query_occupancy(coords, cube_res, model, batchsize, occupancy=None):
+    """The dense query of ``export_mesh`` (modules/volutils.py:113-133): ``model`` is evaluated on ``coords``
+    ((cube_res^3, 3), host or device) in batches of ``batchsize``, ``torch.sigmoid`` of the output fills a
+    (cube_res, cube_res, cube_res) float32 numpy cube -- what the reference then hands to ``mcubes.marching_cubes`` /
+    open3d (out of scope here).  The network forward is the fused HIP path; the sigmoid is wire_sigmoid_inplace."""
+    n = cube_res ** 3
+    if occupancy is None:
+        occupancy = np.zeros((n, 1), dtype=np.float32)
+    else:
+        occupancy[...] = 0
+        occupancy = occupancy.reshape(-1, 1)
+    L = _lib.lib()
+    with torch.no_grad():
+        for b in range(0, n, batchsize):
+            b2 = min(b + batchsize, n)
+            sub = coords[b:b2, :].cuda()
+            y = model(sub).contiguous()
+            _lib.check(L.wire_sigmoid_inplace(torch.cuda.current_stream(y.device).cuda_stream, y.data_ptr(), y.numel()),
+                       "wire_sigmoid_inplace")
+            occupancy[b:b2, :] = y.cpu().numpy()
+    return occupancy.reshape(cube_res, cube_res, cube_res)

@@ -24,8 +24,7 @@ class ComplexGaborLayer2D(ActivationLayer):
     def __init__(self, in_features, out_features, bias=True, is_first=False,
                  omega0=10.0, sigma0=10.0, trainable=False):
         super().__init__()
-        if trainable:
-            raise NotImplementedError("trainable omega_0/scale_0 is not implemented in wire_amd")
+        self.trainable = bool(trainable)
         self.is_first = is_first
         self.in_features = in_features
         self.omega_0 = _scalar_param(omega0, trainable)
@@ -45,6 +44,10 @@ class ComplexGaborLayer2D(ActivationLayer):
                 self.scale_orth.weight, self._bias_or_zeros(self.scale_orth)]
 
     def forward(self, input):
+        if self.trainable:      # omega_0 / scale_0 receive gradients (modules/wire2d.py:42-43 with trainable=True)
+            return Fh.gabor2d_layer_trainable(input, self.linear.weight, self._bias_or_zeros(self.linear),
+                                              self.scale_orth.weight, self._bias_or_zeros(self.scale_orth),
+                                              self.omega_0, self.scale_0, self.is_first)
         return Fh.gabor2d_layer(input, self.linear.weight, self._bias_or_zeros(self.linear),
                                 self.scale_orth.weight, self._bias_or_zeros(self.scale_orth),
                                 self._w, self._s, self.is_first)

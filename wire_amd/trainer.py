@@ -180,6 +180,12 @@ class FusedTrainer:
                 raise ValueError("indices must be contiguous (a strided view such as perm[::2] would be read "
                                  "as its underlying storage); call .contiguous()")
             B = indices.numel()
+            if os.environ.get("WIRE_CHECK_INDICES", "0") == "1" and B > 0:
+                # opt-in (one host sync): the kernels trust the indices, an out-of-range one reads / writes
+                # outside the target and rec buffers
+                lo_i, hi_i = int(indices.min()), int(indices.max())
+                if lo_i < 0 or hi_i >= self.npoints:
+                    raise ValueError(f"indices span [{lo_i}, {hi_i}] outside the grid of {self.npoints} points")
         else:
             B = int(count if count is not None else self.npoints - first)
             if first < 0 or first + B > self.npoints:
