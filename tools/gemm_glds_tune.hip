@@ -51,6 +51,19 @@ int main(int argc, char** argv) {
     ep.o0 = r0; CK(launch_gemmx3_nt(0, EPI_STORE, A, P, Bx3, Nc, P, P, ep));
     std::vector<float> ref((size_t)Nc * P), got((size_t)Nc * P);
     CK(hipMemcpy(ref.data(), r0, ref.size() * 4, hipMemcpyDeviceToHost));
+    gemmx3h_tune_set("x3_h16", 0);
+    {
+      // the 16 x 16 x 32 edition sums the same six products in another grouping: fp32 round-off, not bit equality
+      gemmx3h_tune_set("x3_h16", 3);
+      CK(hipMemset(o0, 0xff, (size_t)Nc * P * 4));
+      ep.o0 = o0; CK(launch_gemmx3_nt(0, EPI_STORE, A, P, Bx3, Nc, P, P, ep));
+      CK(hipMemcpy(got.data(), o0, got.size() * 4, hipMemcpyDeviceToHost));
+      double md = 0, mx = 0;
+      for (size_t i = 0; i < ref.size(); ++i) { md = fmax(md, fabs((double)ref[i] - got[i])); mx = fmax(mx, fabs((double)ref[i])); }
+      printf("check rows %lld  16x16x32 edition vs register-staged: max |diff| %.3e of max |C| %.3e (rel %.2e)\n",
+             (long long)Nc, md, mx, md / mx);
+      gemmx3h_tune_set("x3_h16", 0);
+    }
     for (int mode = 1; mode <= 2; ++mode) {
       gemmx3g_tune_set("x3_glds", mode);
       CK(hipMemset(o0, 0xff, (size_t)Nc * P * 4));
@@ -68,6 +81,11 @@ int main(int argc, char** argv) {
   const double flop = 2.0 * N * P * P;
   struct Var { const char* name; int mode; int epi; int stagger; };
   std::vector<Var> vars = {
+      {"x3h 16x16x32 store", 10, EPI_STORE, 0}, {"x3h 16x16x32 gabor_fwd", 10, EPI_GABOR_FWD, 0},
+      {"x3h 16x16x32 gabor_bwd", 10, EPI_GABOR_BWD, 0},
+      {"x3h fwd stagger 15us", 10, EPI_GABOR_FWD, 1500}, {"x3h fwd stagger 30us", 10, EPI_GABOR_FWD, 3000},
+      {"x3h bwd stagger 15us", 10, EPI_GABOR_BWD, 1500}, {"x3h bwd stagger 30us", 10, EPI_GABOR_BWD, 3000},
+      {"x3h store stagger 30us", 10, EPI_STORE, 3000},
       {"x3  regs  store", 0, EPI_STORE, 0}, {"x3g m1    store", 1, EPI_STORE, 0}, {"x3g m2    store", 2, EPI_STORE, 0},
       {"x3g m1 store stag 20us", 1, EPI_STORE, 2000}, {"x3g m1 store stag 40us", 1, EPI_STORE, 4000},
       {"x3g m1 store stag 60us", 1, EPI_STORE, 6000},
@@ -91,7 +109,9 @@ int main(int argc, char** argv) {
       GemmEpiParams ep;
       ep.bias = bias; ep.o0 = o0; ep.o1 = o1; ep.i0 = lin; ep.i1 = out; ep.ld0 = P; ep.ld1 = P;
       ep.omega = 20.f; ep.scale = 30.f; ep.kvalid = P / 2;
-      gemmx3g_tune_set("x3_glds", V.mode);
+      gemmx3g_tune_set("x3_glds", V.mode == 10 ? 0 : V.mode);
+      gemmx3h_tune_set("x3_h16", V.mode == 10 ? 3 : 0);
+      gemmx3h_tune_set("x3h_stagger", V.mode == 10 ? V.stagger : 0);
       gemmx3g_tune_set("x3_stagger", V.stagger > 0 ? V.stagger : 0);
       gemmx3g_tune_set("x3_stagger_lo", V.stagger < 0 ? -V.stagger : 256);
       CK(hipEventRecord(e0, 0));

@@ -371,7 +371,8 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
   auto out_l = [&](int l) { return save_for_bwd ? A + a.out0 + (int64_t)l * n * p.P
                                                 : A + ((l & 1) ? a.pong : a.ping); };
   auto lin_l = [&](int l) -> float* {
-    if (!save_for_bwd) return nullptr;
+    // relu: out = max(lin, 0) carries everything its backward needs (lin > 0 <=> out > 0): lin is never written
+    if (!save_for_bwd || p.kind == WIRE_KIND_RELU) return nullptr;
     return l == 0 ? A + a.lin0 : A + a.lin1 + (int64_t)(l - 1) * n * p.Pl;
   };
   // ---- layer 0

@@ -165,7 +165,7 @@ WIRE_DEVINL float real_act_bwd(float g, float lin, float out, float w0, float s0
   } else if (ACT == ACT_GAUSS) {
     return g * out * (-2.f * s0 * s0) * lin;
   } else {
-    return lin > 0.f ? g : 0.f;
+    return out > 0.f ? g : 0.f;        // out = max(lin, 0): out > 0 <=> lin > 0, so relu never needs lin stored
   }
 }
 
@@ -193,7 +193,7 @@ WIRE_DEVINL float real_act_bwd_lean(float g, float lin, float out, float w0, flo
   } else if (ACT == ACT_GAUSS) {
     return g * out * (-2.f * s0 * s0) * lin;
   } else {
-    return lin > 0.f ? g : 0.f;
+    return out > 0.f ? g : 0.f;
   }
 }
 

@@ -193,8 +193,9 @@ WIRE_DEVINL void gemm_epilogue(f32x16 (&acc)[MT][WN], const GemmEpiParams& ep, c
             for (int q = 0; q < 8; ++q) {
               const int r = rb0 + q;
               const unsigned off = off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * ldb4;
-              lv[q] = *reinterpret_cast<const float*>(lin_b + off);
-              ov[q] = (ACT == ACT_GAUSS) ? *reinterpret_cast<const float*>(out_b + off) : 0.f;   // only gauss needs out
+              // siren needs lin, relu needs out (lin > 0 <=> out > 0; its lin is never stored), gauss both
+              lv[q] = (ACT != ACT_RELU) ? *reinterpret_cast<const float*>(lin_b + off) : 0.f;
+              ov[q] = (ACT != ACT_SIREN) ? *reinterpret_cast<const float*>(out_b + off) : 0.f;
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -411,7 +412,7 @@ WIRE_DEVINL void gemm_epilogue(f32x16 (&acc)[MT][WN], const GemmEpiParams& ep, c
         for (int r = 0; r < 16; ++r) {
           const int row = m_w + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
           if (row < M) {
-            const float lin = ep.i0[(size_t)row * ep.ld0 + col];
+            const float lin = (ACT != ACT_RELU) ? ep.i0[(size_t)row * ep.ld0 + col] : 0.f;   // relu: lin is not stored
             const float out = ep.i1[(size_t)row * ep.ld1 + col];
             ep.o0[(size_t)row * ep.ld0 + col] =
                 LEAN ? real_act_bwd_lean<ACT>(acc[i][j][r], lin, out, ep.omega, ep.scale)

@@ -106,11 +106,20 @@ __global__ void x3_split_b_kernel(const float* __restrict__ Bt, int ldb, int Nc,
   *reinterpret_cast<unsigned*>(Bx3 + base) = H;
   *reinterpret_cast<unsigned*>(Bx3 + base + 128 * 16) = Mi;
   *reinterpret_cast<unsigned*>(Bx3 + base + 2 * 128 * 16) = L;
+  // second image, same order WITHOUT the swizzle: the 16 x 16 x 32 fragment reads of wire_gemmx3h.hip (16 columns x
+  // one 8-k half per 16-lane group) are conflict-free on the plain [column][16 k] rows
+  unsigned short* Bu = Bx3 + (size_t)gridDim.y * nk * 3 * 16;
+  const size_t ubase = ((size_t)(ct * nk + kt) * 3 * 128 + c) * 16 + kk;
+  *reinterpret_cast<unsigned*>(Bu + ubase) = H;
+  *reinterpret_cast<unsigned*>(Bu + ubase + 128 * 16) = Mi;
+  *reinterpret_cast<unsigned*>(Bu + ubase + 2 * 128 * 16) = L;
 }
 
 int64_t gemmx3_b_image_floats(int Nc, int Kd) {
   const int64_t tiles_n = (Nc + X3_BN - 1) / X3_BN;
-  return tiles_n * 128 * (int64_t)Kd * 3 / 2;     // 3 bf16 planes = 1.5 floats per element
+  // 3 bf16 planes = 1.5 floats per element; two images (bank-swizzled for the 32 x 32 x 16 kernels, plain for the
+  // 16 x 16 x 32 kernel): the second starts gemmx3_b_image_floats() USHORTS into the buffer
+  return tiles_n * 128 * (int64_t)Kd * 3;
 }
 
 hipError_t launch_x3_split_b(hipStream_t s, const float* Bt, int ldb, int Nc, int Kd, void* Bx3) {
@@ -338,6 +347,7 @@ int gemmx3_tune_set(const char* key, int value) {
   if (!strcmp(key, "x3_tall") && (value == 0 || value == 1)) { g_x3_tall = value; return 0; }
   if (!strcmp(key, "x3_tn_tall") && (value == 0 || value == 1)) { g_x3_tn_tall = value; return 0; }
   if (!strcmp(key, "x3_tall_real") && (value == 0 || value == 1)) { g_x3_tall_real = value; return 0; }
+  if (gemmx3h_tune_set(key, value) == 0) return 0;
   return gemmx3g_tune_set(key, value);
 }
 
@@ -345,6 +355,7 @@ hipError_t launch_gemmx3_nt(hipStream_t s, int epi, const float* A, int lda, con
                             int Nc, int Kd, const GemmEpiParams& ep_in) {
   if (M <= 0) return hipSuccess;
   if (gemmx3g_handles(epi, M)) return launch_gemmx3g_nt(s, epi, A, lda, Bx3, M, Nc, Kd, ep_in);   // LDS-DMA edition
+  if (gemmx3h_handles(epi, M)) return launch_gemmx3h_nt(s, epi, A, lda, Bx3, M, Nc, Kd, ep_in);   // 16 x 16 x 32 edition
   if ((Nc & 63) || (Kd & 31) || (lda & 3) || M > 0x7fffff00LL) return hipErrorInvalidValue;
   // the lean Gabor epilogues share one 32-bit byte offset between their buffers
   GemmEpiParams ep = ep_in;

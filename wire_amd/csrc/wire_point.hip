@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(
           if (KIND == NK_WIRE2D) {
             const float* L = lin + row * Pl + lc;
             l0[q] = L[0]; l1[q] = L[32]; l2[q] = L[64]; l3[q] = L[96];
-          } else {
+          } else if (KIND != NK_RELU) {             // relu: lin is not stored (lin > 0 <=> out > 0)
             l0[q] = lin[row * P + c0];
             if (KIND == NK_WIRE) l1[q] = lin[row * P + c0 + 32];
           }
