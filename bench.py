@@ -332,7 +332,9 @@ def main():
         value = npts * args.steps / dt
         split = lib.wire_tune_get(b"split_bf16") == 1
         if split:
-            names = ["gemmx3_nt<gabor_fwd> (layer forward)", "gemmx3_nt<gabor_bwd> (data gradient)",
+            h16 = lib.wire_tune_get(b"x3_h16")
+            names = [("gemmx3h_nt<gabor_fwd> (layer forward, 16x16x32 MFMA)" if h16 & 1 else "gemmx3_nt<gabor_fwd> (layer forward)"),
+                     ("gemmx3h_nt<gabor_bwd> (data gradient, 16x16x32 MFMA)" if h16 & 2 else "gemmx3_nt<gabor_bwd> (data gradient)"),
                      "gemmx3_tn (weight gradient)", "other"]
             peak = PEAK_BF16_MFMA_TFLOPS / 6.0          # 6 bf16 partial products per fp32 product
         else:

@@ -114,6 +114,7 @@ extern "C" int wire_tune_get(const char* key) {
   if (!key) return fail(WIRE_ERR_ARG, "null key");
   if (!strcmp(key, "complex_3m")) return g_complex_3m;
   if (!strcmp(key, "split_bf16")) return g_split_bf16;
+  if (!strcmp(key, "x3_h16")) return gemmx3h_mode();
   return fail(WIRE_ERR_ARG, "unknown tuning key: %s", key);
 }
 extern "C" int wire_tune_set(const char* key, int value) {

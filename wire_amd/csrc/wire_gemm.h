@@ -88,5 +88,6 @@ hipError_t launch_gemmx3g_nt(hipStream_t s, int epi, const float* A, int lda, co
 // ---- 16 x 16 x 32 edition (wire_gemmx3h.hip): reads the second (unswizzled) half of the split image
 bool gemmx3h_handles(int epi, int64_t M);
 int gemmx3h_tune_set(const char* key, int value);
+int gemmx3h_mode();
 hipError_t launch_gemmx3h_nt(hipStream_t s, int epi, const float* A, int lda, const void* Bx3, int64_t M,
                              int Nc, int Kd, const GemmEpiParams& ep);

@@ -398,6 +398,7 @@ int gemmx3h_tune_set(const char* key, int value) {
   if (!strcmp(key, "x3h_stagger") && value >= 0) { g_x3h_stagger = value; return 0; }
   return -1;
 }
+int gemmx3h_mode() { return g_x3_h16; }
 bool gemmx3h_handles(int epi, int64_t M) {
   if (!g_x3_h16 || M < 4096) return false;
   if (epi == EPI_STORE || epi == EPI_GABOR_FWD) return (g_x3_h16 & 1) != 0;
