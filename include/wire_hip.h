@@ -274,8 +274,8 @@ int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* 
  *     MAC); 0 = 4-multiplication real-expanded GEMMs.
  * "x3_tall" (default 1), "x3_tn_tall" (default 0): 256-row tiles in the split-bf16
  *     NT / TN kernels.   "nt_bk" (16 | 32): K-slab depth of the fp32 4M NT kernel.
- * "x3_h16" (default 3): bit 0 / bit 1 = the v_mfma_f32_16x16x32_bf16 edition (wire_gemmx3h.hip) for the
- *     forward / data-gradient GEMMs of the wire kernels at M >= 4096; 0 = the 32x32x16 kernels.
+ * "x3_h16" (default 15): the v_mfma_f32_16x16x32_bf16 edition (wire_gemmx3h.hip) of the NT GEMMs at M >= 4096:
+ *     bit 0 wire forward, bit 1 wire data gradient, bit 2 siren / gauss / relu, bit 3 wire2d; 0 = the 32x32x16 kernels.
  * "x3_glds" (default 0): 1 / 2 = LDS-DMA 32x32x16 editions of the split-bf16 NT GEMM at M >= 4096
  *     (wire_gemmx3g.hip).  All editions give bit-identical GEMM results.
  * Neither buffer sizes (wire_packed_floats, wire_act_bytes, wire_bwd_scratch_bytes) nor

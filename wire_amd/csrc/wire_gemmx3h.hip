@@ -121,6 +121,199 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
         if (row + 8 < M) *reinterpret_cast<f32x4*>(ep.o0 + (size_t)(row + 8) * ep.ld0 + col) = yp;
       }
     }
+  } else if constexpr (EPI == EPI_SIREN_FWD || EPI == EPI_GAUSS_FWD || EPI == EPI_RELU_FWD) {
+    constexpr int ACT = EPI - EPI_SIREN_FWD;
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) {
+      if (n_w + 32 * sp >= Nc) continue;
+      const int col = n_w + 32 * sp + cq;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(ep.bias + col);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        f32x4 a2[2];
+        h_pair_rows(acc[rb][2 * sp], acc[rb][2 * sp + 1], a2[0], a2[1]);
+#pragma unroll
+        for (int hr = 0; hr < 2; ++hr) {
+          const int row = m_w + 16 * rb + 8 * hr + rr;
+          f32x4 lin, o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            lin[q] = a2[hr][q] + bv[q];
+            const float v = real_act_fwd_lean<ACT>(lin[q], ep.omega, ep.scale);
+            o[q] = col + q < ep.kvalid ? v : 0.f;                  // pad features are written as 0
+          }
+          if (row < M) {
+            if (ep.o0) *reinterpret_cast<f32x4*>(ep.o0 + (size_t)row * ep.ld0 + col) = lin;
+            *reinterpret_cast<f32x4*>(ep.o1 + (size_t)row * ep.ld1 + col) = o;
+          }
+        }
+      }
+    }
+  } else if constexpr (EPI == EPI_SIREN_BWD || EPI == EPI_GAUSS_BWD || EPI == EPI_RELU_BWD) {
+    constexpr int ACT = EPI - EPI_SIREN_BWD;
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) {
+      if (n_w + 32 * sp >= Nc) continue;
+      const int col = n_w + 32 * sp + cq;
+#pragma unroll
+      for (int rp = 0; rp < 4; rp += 2) {
+        f32x4 lv[4], ov[4], a2[4];
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+          h_pair_rows(acc[rp + r2][2 * sp], acc[rp + r2][2 * sp + 1], a2[2 * r2], a2[2 * r2 + 1]);
+#pragma unroll
+          for (int hr = 0; hr < 2; ++hr) {
+            int row = m_w + 16 * (rp + r2) + 8 * hr + rr;
+            row = row < M ? row : M - 1;
+            // siren needs lin, relu needs out (its lin is never stored), gauss both
+            lv[2 * r2 + hr] = (ACT != ACT_RELU) ? *reinterpret_cast<const f32x4*>(ep.i0 + (size_t)row * ep.ld0 + col)
+                                                : f32x4{0.f, 0.f, 0.f, 0.f};
+            ov[2 * r2 + hr] = (ACT != ACT_SIREN) ? *reinterpret_cast<const f32x4*>(ep.i1 + (size_t)row * ep.ld1 + col)
+                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = m_w + 16 * (rp + (e >> 1)) + 8 * (e & 1) + rr;
+          f32x4 gl;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gl[q] = real_act_bwd_lean<ACT>(a2[e][q], lv[e][q], ov[e][q], ep.omega, ep.scale);
+          if (row < M) *reinterpret_cast<f32x4*>(ep.o0 + (size_t)row * ep.ld0 + col) = gl;
+        }
+      }
+    }
+  } else if constexpr (EPI == EPI_GABOR2D_FWD) {
+    // the wave's 128 columns = (lin_re | lin_im | sy_re | sy_im) of 32 features (modules/wire2d.py:56-67)
+    const int grp = n_w >> 7;
+    const int f0 = (grp << 5) + cq;                               // features f0 .. f0 + 3
+    const int oc = (grp << 6) + cq;                               // re column in the P-wide output row; im = + 32
+    f32x4 bv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bv[k] = *reinterpret_cast<const f32x4*>(ep.bias + n_w + 32 * k + cq);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      f32x4 part[4][2];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) h_pair_rows(acc[rb][2 * k], acc[rb][2 * k + 1], part[k][0], part[k][1]);
+#pragma unroll
+      for (int hr = 0; hr < 2; ++hr) {
+        const int row = m_w + 16 * rb + 8 * hr + rr;
+        f32x4 u, v, pp, qq, o_re, o_im;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          u[q] = part[0][hr][q] + bv[0][q];
+          v[q] = part[1][hr][q] + bv[1][q];
+          pp[q] = part[2][hr][q] + bv[2][q];
+          qq[q] = part[3][hr][q] + bv[3][q];
+          float a, b;
+          gabor2d_fwd_lean(u[q], v[q], pp[q], qq[q], ep.omega, ep.scale, a, b);
+          const bool valid = f0 + q < ep.kvalid;
+          o_re[q] = valid ? a : 0.f;
+          o_im[q] = valid ? b : 0.f;
+        }
+        if (row < M) {
+          if (ep.o0) {
+            float* Lp = ep.o0 + (size_t)row * ep.ld0 + n_w + cq;
+            *reinterpret_cast<f32x4*>(Lp) = u;
+            *reinterpret_cast<f32x4*>(Lp + 32) = v;
+            *reinterpret_cast<f32x4*>(Lp + 64) = pp;
+            *reinterpret_cast<f32x4*>(Lp + 96) = qq;
+          }
+          float* Op = ep.o1 + (size_t)row * ep.ld1 + oc;
+          *reinterpret_cast<f32x4*>(Op) = o_re;
+          *reinterpret_cast<f32x4*>(Op + 32) = o_im;
+        }
+      }
+    }
+  } else if constexpr (EPI == EPI_GABOR2D_BWD || EPI == EPI_GABOR2D_BWD_FIRST) {
+    // C = g_out (re | im pairs, P wide); writes g_(lin | sy) into the 2P-wide row (or the real g_(u | p) of layer 0)
+    const float m2s2 = -2.f * ep.scale * ep.scale, w0 = ep.omega;
+#pragma unroll
+    for (int G = 0; G < 2; ++G) {
+      if (n_w + 64 * G >= Nc) continue;
+      const int c0 = n_w + 64 * G + cq;                           // re column of g_out / out; im = + 32
+      const int grp = c0 >> 6;
+      const int f0 = (grp << 5) + (c0 & 31);
+      const int lc = (grp << 7) + (c0 & 31);                      // lin_re column in the 2P row
+      float w[4][4], wv[4][4], bb[4], bv2[4];
+      if constexpr (EPI == EPI_GABOR2D_BWD_FIRST) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool valid = f0 + q < ep.kvalid;
+          bb[q] = valid ? ep.b0[f0 + q] : 0.f;
+          bv2[q] = valid ? ep.b0b[f0 + q] : 0.f;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            w[q][d] = (valid && d < ep.D) ? ep.W0[(f0 + q) * ep.D + d] : 0.f;
+            wv[q][d] = (valid && d < ep.D) ? ep.W0b[(f0 + q) * ep.D + d] : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        f32x4 are[2], aim[2];
+        h_pair_rows(acc[rb][4 * G], acc[rb][4 * G + 1], are[0], are[1]);
+        h_pair_rows(acc[rb][4 * G + 2], acc[rb][4 * G + 3], aim[0], aim[1]);
+        f32x4 u[2], v[2], pp[2], qq[2], pr[2], pi[2];
+#pragma unroll
+        for (int hr = 0; hr < 2; ++hr) {
+          int row = m_w + 16 * rb + 8 * hr + rr;
+          row = row < M ? row : M - 1;
+          const float* Op = ep.i1 + (size_t)row * ep.ld1 + c0;
+          pr[hr] = *reinterpret_cast<const f32x4*>(Op);
+          pi[hr] = *reinterpret_cast<const f32x4*>(Op + 32);
+          if constexpr (EPI == EPI_GABOR2D_BWD) {
+            const float* Lp = ep.i0 + (size_t)row * ep.ld0 + lc;
+            u[hr] = *reinterpret_cast<const f32x4*>(Lp);
+            v[hr] = *reinterpret_cast<const f32x4*>(Lp + 32);
+            pp[hr] = *reinterpret_cast<const f32x4*>(Lp + 64);
+            qq[hr] = *reinterpret_cast<const f32x4*>(Lp + 96);
+          } else {
+            float x[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int d = 0; d < ep.D; ++d) x[d] = ep.coords[(size_t)row * ep.D + d];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float uu = bb[q], p2 = bv2[q];
+#pragma unroll
+              for (int d = 0; d < 4; ++d) { uu = __builtin_fmaf(x[d], w[q][d], uu); p2 = __builtin_fmaf(x[d], wv[q][d], p2); }
+              u[hr][q] = uu; pp[hr][q] = p2; v[hr][q] = 0.f; qq[hr][q] = 0.f;
+            }
+          }
+        }
+#pragma unroll
+        for (int hr = 0; hr < 2; ++hr) {
+          const int row = m_w + 16 * rb + 8 * hr + rr;
+          f32x4 g0, g1, g2, g3;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float gr = are[hr][q], gi = aim[hr][q];
+            const float c_r = __builtin_fmaf(pr[hr][q], gr, pi[hr][q] * gi);
+            const float c_i = __builtin_fmaf(pr[hr][q], gi, -(pi[hr][q] * gr));
+            const float tt = m2s2 * c_r;
+            g0[q] = __builtin_fmaf(tt, u[hr][q], w0 * c_i);      // g_lin = -2 s^2 P lin - j w0 c  (real part / real first layer)
+            g1[q] = __builtin_fmaf(tt, v[hr][q], -(w0 * c_r));
+            g2[q] = tt * pp[hr][q];                               // g_sy = -2 s^2 P sy
+            g3[q] = tt * qq[hr][q];
+          }
+          if (row < M) {
+            if constexpr (EPI == EPI_GABOR2D_BWD) {
+              float* Gp = ep.o0 + (size_t)row * ep.ld0 + lc;
+              *reinterpret_cast<f32x4*>(Gp) = g0;
+              *reinterpret_cast<f32x4*>(Gp + 32) = g1;
+              *reinterpret_cast<f32x4*>(Gp + 64) = g2;
+              *reinterpret_cast<f32x4*>(Gp + 96) = g3;
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (!(f0 + q < ep.kvalid)) { g0[q] = 0.f; g2[q] = 0.f; }
+              float* Gp = ep.o0 + (size_t)row * (2 * ep.ldu);
+              *reinterpret_cast<f32x4*>(Gp + f0) = g0;
+              *reinterpret_cast<f32x4*>(Gp + ep.ldu + f0) = g2;
+            }
+          }
+        }
+      }
+    }
   } else {
     // complex epilogues: 64-column groups (re | im of 32 features) = blocks 4 G, 4 G + 1 (re) and 4 G + 2, 4 G + 3 (im)
     const float w0 = ep.omega, w0l2e = ep.omega * 1.44269502f, ns2l2e = -(ep.scale * ep.scale) * 1.44269502f;
@@ -391,10 +584,12 @@ static int x3h_env(const char* name, int dflt) {
 }
 // bit 0: forward / store epilogues, bit 1: data-gradient epilogues.  In bench.py (same box, interleaved runs,
 // profiles/r02_bench_h16_ab.txt): forward launches 0.758 -> 0.700 ms, data gradient 0.749 -> 0.739 ms, step 9.93 -> 9.63 ms
-static int g_x3_h16 = x3h_env("WIRE_X3_H16", 3);
+// bit 2: siren / gauss / relu epilogues, bit 3: the 2-D Gabor epilogues (sweep A/B, same box: siren 72.4 -> 74.9,
+// relu 81.9 -> 85.0, wire2d 44.2 -> 47.6 M samples/s)
+static int g_x3_h16 = x3h_env("WIRE_X3_H16", 15);
 static int g_x3h_stagger = x3h_env("WIRE_X3H_STAGGER", 0);      // 100 MHz ticks (100 = 1 us)
 int gemmx3h_tune_set(const char* key, int value) {
-  if (!strcmp(key, "x3_h16") && value >= 0 && value <= 3) { g_x3_h16 = value; return 0; }
+  if (!strcmp(key, "x3_h16") && value >= 0 && value <= 15) { g_x3_h16 = value; return 0; }
   if (!strcmp(key, "x3h_stagger") && value >= 0) { g_x3h_stagger = value; return 0; }
   return -1;
 }
@@ -403,6 +598,8 @@ bool gemmx3h_handles(int epi, int64_t M) {
   if (!g_x3_h16 || M < 4096) return false;
   if (epi == EPI_STORE || epi == EPI_GABOR_FWD) return (g_x3_h16 & 1) != 0;
   if (epi == EPI_GABOR_BWD || epi == EPI_GABOR_BWD_FIRST) return (g_x3_h16 & 2) != 0;
+  if (epi >= EPI_SIREN_FWD && epi <= EPI_RELU_BWD) return (g_x3_h16 & 4) != 0;
+  if (epi >= EPI_GABOR2D_FWD && epi <= EPI_GABOR2D_BWD_FIRST) return (g_x3_h16 & 8) != 0;
   return false;
 }
 
@@ -419,6 +616,17 @@ hipError_t launch_gemmx3h_nt(hipStream_t s, int epi, const float* A, int lda, co
     case EPI_GABOR_FWD: return launchx3h_t<EPI_GABOR_FWD>(s, A, lda, Bu, M, Nc, Kd, ep);
     case EPI_GABOR_BWD: return launchx3h_t<EPI_GABOR_BWD>(s, A, lda, Bu, M, Nc, Kd, ep);
     case EPI_GABOR_BWD_FIRST: return launchx3h_t<EPI_GABOR_BWD_FIRST>(s, A, lda, Bu, M, Nc, Kd, ep);
+    case EPI_SIREN_FWD: return launchx3h_t<EPI_SIREN_FWD>(s, A, lda, Bu, M, Nc, Kd, ep);
+    case EPI_GAUSS_FWD: return launchx3h_t<EPI_GAUSS_FWD>(s, A, lda, Bu, M, Nc, Kd, ep);
+    case EPI_RELU_FWD: return launchx3h_t<EPI_RELU_FWD>(s, A, lda, Bu, M, Nc, Kd, ep);
+    case EPI_SIREN_BWD: return launchx3h_t<EPI_SIREN_BWD>(s, A, lda, Bu, M, Nc, Kd, ep);
+    case EPI_GAUSS_BWD: return launchx3h_t<EPI_GAUSS_BWD>(s, A, lda, Bu, M, Nc, Kd, ep);
+    case EPI_RELU_BWD: return launchx3h_t<EPI_RELU_BWD>(s, A, lda, Bu, M, Nc, Kd, ep);
+    case EPI_GABOR2D_FWD:
+      if (Nc & 127) return hipErrorInvalidValue;
+      return launchx3h_t<EPI_GABOR2D_FWD>(s, A, lda, Bu, M, Nc, Kd, ep);
+    case EPI_GABOR2D_BWD: return launchx3h_t<EPI_GABOR2D_BWD>(s, A, lda, Bu, M, Nc, Kd, ep);
+    case EPI_GABOR2D_BWD_FIRST: return launchx3h_t<EPI_GABOR2D_BWD_FIRST>(s, A, lda, Bu, M, Nc, Kd, ep);
     default: return hipErrorInvalidValue;
   }
 }
