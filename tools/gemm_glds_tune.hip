@@ -123,6 +123,23 @@ int main(int argc, char** argv) {
       if (r > 0) { sum[v] += ms; if (ms < best[v]) best[v] = ms; }
     }
   }
+  // ---- weight-gradient (TN) kernel: slab[s] = G^T Z over row splits
+  {
+    const int S = gemmx3_tn_splits(N, P, P, 192);
+    float* slab; CK(hipMalloc(&slab, (size_t)S * P * P * 4));
+    float* bslab; CK(hipMalloc(&bslab, (size_t)S * P * 4));
+    double tsum = 0;
+    for (int r = 0; r < rounds + 1; ++r) {
+      CK(hipEventRecord(e0, 0));
+      for (int q = 0; q < 4; ++q) CK(launch_gemmx3_tn(0, A, P, out, P, N, P, P, S, slab, bslab));
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (r > 0) tsum += ms / 4;
+    }
+    printf("  %-22s mean %7.3f ms  (%d row splits)  -> %6.1f alg TF  frac %.3f\n", "x3 tn wgrad", tsum / rounds, S,
+           flop / (tsum / rounds * 1e-3) / 1e12, flop / (tsum / rounds * 1e-3) / 1e12 / 416.7);
+  }
   printf("N=%lld P=%d  (%.1f algorithmic GFLOP per launch; split roofline 416.7 TF)\n", (long long)N, P, flop / 1e9);
   for (size_t v = 0; v < vars.size(); ++v) {
     const double tf = flop / (sum[v] / rounds * 1e-3) / 1e12;

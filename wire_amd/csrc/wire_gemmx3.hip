@@ -80,7 +80,20 @@ WIRE_DEVINL Split2 split2(float x0, float x1) {
 // byte offset of (row, 16-byte half) inside a 128-row x 32-byte operand plane
 WIRE_DEVINL int x3_off(int row, int half) { return row * 32 + ((half ^ ((row >> 3) & 1)) << 4); }
 
+#ifdef WIRE_PROBE16
+// probe only (results wrong; tools/build_glds_tune.sh): the same flops as two 16x16x32 MFMAs on quarters of the accumulator
+typedef float x3f32x4 __attribute__((ext_vector_type(4)));
+#define X3_MFMA(a, b, c)                                                                                  \
+  do {                                                                                                    \
+    x3f32x4 q0_ = {c[0], c[1], c[2], c[3]}, q1_ = {c[4], c[5], c[6], c[7]};                               \
+    q0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q0_, 0, 0, 0);                                    \
+    q1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q1_, 0, 0, 0);                                    \
+    c[0] = q0_[0]; c[1] = q0_[1]; c[2] = q0_[2]; c[3] = q0_[3];                                           \
+    c[4] = q1_[0]; c[5] = q1_[1]; c[6] = q1_[2]; c[7] = q1_[3];                                           \
+  } while (0)
+#else
 #define X3_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
 
 // ---------------------------------------------------------------------------
 // weights: fp32 image Bt[Nc][ldb] -> stage-major split image
