@@ -335,7 +335,8 @@ def main():
             h16 = lib.wire_tune_get(b"x3_h16")
             names = [("gemmx3h_nt<gabor_fwd> (layer forward, 16x16x32 MFMA)" if h16 & 1 else "gemmx3_nt<gabor_fwd> (layer forward)"),
                      ("gemmx3h_nt<gabor_bwd> (data gradient, 16x16x32 MFMA)" if h16 & 2 else "gemmx3_nt<gabor_bwd> (data gradient)"),
-                     "gemmx3_tn (weight gradient)", "other"]
+                     ("gemmx3_tn16 (weight gradient, 16x16x32 MFMA)" if lib.wire_tune_get(b"x3_tn16") == 1 and (2 * K) % 256 == 0
+                      else "gemmx3_tn (weight gradient)"), "other"]
             peak = PEAK_BF16_MFMA_TFLOPS / 6.0          # 6 bf16 partial products per fp32 product
         else:
             names = ["gemm3m_nt<gabor_fwd> (layer forward)", "gemm3m_nt<gabor_bwd> (data gradient)",

@@ -276,6 +276,8 @@ int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* 
  *     NT / TN kernels.   "nt_bk" (16 | 32): K-slab depth of the fp32 4M NT kernel.
  * "x3_h16" (default 15): the v_mfma_f32_16x16x32_bf16 edition (wire_gemmx3h.hip) of the NT GEMMs at M >= 4096:
  *     bit 0 wire forward, bit 1 wire data gradient, bit 2 siren / gauss / relu, bit 3 wire2d; 0 = the 32x32x16 kernels.
+ * "x3_tn16" (default 1): the weight-gradient (TN) GEMM of the split-bf16 family runs its 256 x 256-tile
+ *     v_mfma_f32_16x16x32_bf16 kernel when both padded widths are multiples of 256; 0 = the 128 x 128 kernel.
  * "x3_glds" (default 0): 1 / 2 = LDS-DMA 32x32x16 editions of the split-bf16 NT GEMM at M >= 4096
  *     (wire_gemmx3g.hip).  All editions give bit-identical GEMM results.
  * Neither buffer sizes (wire_packed_floats, wire_act_bytes, wire_bwd_scratch_bytes) nor
@@ -283,7 +285,7 @@ int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* 
  * family, activations are fp32 blocked rows for all of them, so a knob may change between
  * a forward and its backward.                                                  */
 int wire_tune_set(const char* key, int value);
-int wire_tune_get(const char* key);   /* "split_bf16" | "complex_3m" | "x3_h16" -> value; < 0 = error */
+int wire_tune_get(const char* key);   /* "split_bf16" | "complex_3m" | "x3_h16" | "x3_tn16" -> value; < 0 = error */
 
 /* ---- profiling hooks (bench.py roofline) -------------------------------
  * When enabled, every launch of the hot kernels is bracketed by hipEvents on

@@ -1,7 +1,8 @@
 """Parity protocol of SURVEY.md section 7 ON THE KERNELS bench.py TIMES.
 
 bench.py's step runs ``gemmx3_nt<EPI, 4, 2>`` (256-row tiles, selected at M >= 4096, lean hardware-transcendental
-epilogues), ``gemmx3_tn<2>`` with a 48-way row split, and ``final_fused_kernel``.  The fixtures of
+epilogues; at M >= 4096 their 16x16x32 edition ``gemmx3h_nt``), ``gemmx3_tn16`` with a 64-way row split, and
+``final_fused_kernel``.  The fixtures of
 tests/golden hold <= 512 rows, which select the 128-row tiles.  Here every check runs at row counts and widths
 that select the timed code:
 
@@ -82,6 +83,40 @@ def test_gabor_layers_identical_inputs_at_timed_shape(fam, cfg):
             assert max(e_w, e_x, e_b) <= 2e-5, f"{fam} {cfg} layer {i} backward W {e_w:.2e} x {e_x:.2e} b {e_b:.2e}"
             print(f"{fam} {cfg} layer {i}: fwd {e_fwd:.2e}  gW {e_w:.2e}  gx {e_x:.2e}  gb {e_b:.2e}")
             x_np = out64.astype(np.complex64)           # identical (rounded) input for the next layer
+
+
+@pytest.mark.parametrize("n", [300, N_TALL, 16384 + 21])
+@pytest.mark.parametrize("tn16", [0, 1])
+def test_weight_gradient_kernels_vs_fp64(tn16, n):
+    """The two split-bf16 weight-gradient kernels (wire_gemmx3.hip: gemmx3_tn_kernel, 128 x 128 tiles on the
+    32x32x16 MFMA; gemmx3_tn16_kernel, 256 x 256 tiles on the 16x16x32 MFMA -- the one bench.py times, knob
+    "x3_tn16") on a hidden ComplexGaborLayer's backward (autograd of modules/wire.py:89): dW = g_lin^T conj(x),
+    db = sum g_lin, at row counts with one row split, a ragged last stage and many splits."""
+    from wire_amd import _lib
+    om, sc = 20.0, 30.0
+    model = _wire_model(1, om, sc)
+    P64 = wo.cast_params(params_np(model), True)
+    W, b = P64["net.1.linear.weight"], P64["net.1.linear.bias"]
+    rng = np.random.default_rng(n)
+    x_np = (0.3 * (rng.standard_normal((n, 256)) + 1j * rng.standard_normal((n, 256)))).astype(np.complex64)
+    g = (rng.standard_normal((n, 256)) + 1j * rng.standard_normal((n, 256))).astype(np.complex64)
+    lin64 = x_np.astype(np.complex128) @ W.T + b
+    out64 = wo.gabor_act(lin64, om, sc)
+    gl = wo.gabor_act_grad(g.astype(np.complex128), lin64, out64, om, sc)
+    L = _lib.lib()
+    assert L.wire_tune_get(b"x3_tn16") == 1              # the default is the timed kernel
+    _lib.check(L.wire_tune_set(b"x3_tn16", tn16))
+    try:
+        x = torch.tensor(x_np, device=DEV, requires_grad=True)
+        model.zero_grad()
+        model.net[1](x).backward(torch.tensor(g, device=DEV))
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(L.wire_tune_set(b"x3_tn16", 1))
+    lw = model.net[1].linear
+    e_w = relmax(lw.weight.grad.cpu().numpy(), gl.T @ np.conj(x_np.astype(np.complex128)))
+    e_b = relmax(lw.bias.grad.cpu().numpy(), gl.sum(0))
+    assert max(e_w, e_b) <= 2e-5, f"tn16={tn16} n={n}: gW {e_w:.2e} gb {e_b:.2e}"
 
 
 @pytest.mark.parametrize("fam", ["x3", "4m"])
@@ -212,7 +247,7 @@ STEP_CASES = {
 def test_fused_trainer_step_gradients_vs_fp64_oracle(case):
     """One FusedTrainer.step (lr = 0, a random permutation of the whole grid as the batch -- wire_image_denoise.py:
     142-157, wire_occupancy.py:137-158) at the bench's architecture.  N = 16 384 and 262 144 rows run
-    gemmx3_nt<.,4,2>, final_fused_kernel and the row-split gemmx3_tn exactly as bench.py does.  Output, loss and
+    gemmx3h_nt, final_fused_kernel and the row-split gemmx3_tn16 exactly as bench.py does (the 3 x 300 case: gemmx3_tn).  Output, loss and
     EVERY parameter gradient against the numpy fp64 oracle on the same weights; yardstick = the same oracle in
     fp32 (the reference arithmetic's own round-off): err_build <= 2 err_ref + 1e-6."""
     from wire_amd.trainer import FusedTrainer

@@ -115,6 +115,7 @@ extern "C" int wire_tune_get(const char* key) {
   if (!strcmp(key, "complex_3m")) return g_complex_3m;
   if (!strcmp(key, "split_bf16")) return g_split_bf16;
   if (!strcmp(key, "x3_h16")) return gemmx3h_mode();
+  if (!strcmp(key, "x3_tn16")) return gemmx3_tn16_mode();
   return fail(WIRE_ERR_ARG, "unknown tuning key: %s", key);
 }
 extern "C" int wire_tune_set(const char* key, int value) {
@@ -244,7 +245,7 @@ ScratchLayout scratch_layout(const Plan& p, int64_t n) {
   const int64_t pn = p.first_gemm && p.Pin0 > p.P ? p.Pin0 : p.P;
   // slabs sized for the largest split count of the three GEMM families (flag-independent scratch size)
   // (the split-bf16 kernel may split finer: narrow nets have few tiles and would otherwise leave CUs idle)
-  const int s_x3 = gemmx3_tn_splits(n, p.Pl, (int)pn, 192), s_4m = gemm_tn_splits(n, p.Pl, (int)pn, 64);
+  const int s_x3 = gemmx3_tn_splits_max(n, p.Pl, (int)pn, 192), s_4m = gemm_tn_splits(n, p.Pl, (int)pn, 64);
   const int s_max = s_x3 > s_4m ? s_x3 : s_4m;
   if (p.m3) {
     s.S = gemm3m_tn_splits(n, p.Kp, p.Kp, 64);

@@ -74,7 +74,9 @@ hipError_t launch_x3_split_b(hipStream_t s, const float* Bt, int ldb, int Nc, in
 hipError_t launch_gemmx3_nt(hipStream_t s, int epi, const float* A, int lda, const void* Bx3, int64_t M,
                             int Nc, int Kd, const GemmEpiParams& ep);
 int gemmx3_tune_set(const char* key, int value);
+int gemmx3_tn16_mode();
 int gemmx3_tn_splits(int64_t n, int Pm, int Pn, int max_splits);
+int gemmx3_tn_splits_max(int64_t n, int Pm, int Pn, int max_splits);   // over the "x3_tn16" settings (scratch sizing)
 hipError_t launch_gemmx3_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n,
                             int Pm, int Pn, int splits, float* slab, float* bslab);
 

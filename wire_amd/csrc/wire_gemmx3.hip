@@ -352,13 +352,16 @@ static int x3_env(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 static int g_x3_tn_tall = x3_env("WIRE_X3_TN_TALL", 0);   // 256 x 128 tiles in the weight-gradient kernel
+static int g_x3_tn16 = x3_env("WIRE_X3_TN16", 1);         // 256 x 256 tiles on v_mfma_f32_16x16x32_bf16
 // 256-row tiles (4 x 2 MFMA tiles per wave) for the Gabor epilogues of large batches: fewer weight bytes
 // per MFMA through the 64 B/clk L1 path (tools/mfma_bf16_probe.hip), 7-9 % faster at N = 262144
 static int g_x3_tall = x3_env("WIRE_X3_TALL", 1);
 static int g_x3_tall_real = x3_env("WIRE_X3_TALL_REAL", 0);   // the same for siren / gauss / relu (A/B switch)
+int gemmx3_tn16_mode() { return g_x3_tn16; }
 int gemmx3_tune_set(const char* key, int value) {
   if (!strcmp(key, "x3_tall") && (value == 0 || value == 1)) { g_x3_tall = value; return 0; }
   if (!strcmp(key, "x3_tn_tall") && (value == 0 || value == 1)) { g_x3_tn_tall = value; return 0; }
+  if (!strcmp(key, "x3_tn16") && (value == 0 || value == 1)) { g_x3_tn16 = value; return 0; }
   if (!strcmp(key, "x3_tall_real") && (value == 0 || value == 1)) { g_x3_tall_real = value; return 0; }
   if (gemmx3h_tune_set(key, value) == 0) return 0;
   return gemmx3g_tune_set(key, value);
@@ -642,18 +645,272 @@ __global__ __launch_bounds__(256, (MT > 2 ? 2 : 3)) void gemmx3_tn_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// TN GEMM, 16 x 16 x 32 edition (both padded widths multiples of 256; knob "x3_tn16").
+//
+// The 128 x 128 kernel above spends 88 split operations per 48 MFMAs of a wave and stage; with the 16-cycle
+// instruction shape that mix is bound by vector issue, not by the matrix cores (probe: -3 %).  Here a workgroup of
+// 8 waves owns 256 features of G x 256 features of Z: each of the 16 x (256 + 256) fp32 values of a stage is still
+// split once, but feeds twice the MFMAs -- 88 vector operations beside 96 MFMAs per wave and stage.
+//
+//  * plane pairing as in wire_gemmx3h.hip: lanes 0-31 of a fragment carry the 16 rows (k) of the stage for one
+//    plane, lanes 32-63 the same 16 rows for another, so one instruction sums two of the six partial products:
+//        Z operand (h | l) x G operand (l | h)      ->  h l + l h
+//        Z operand (m | h) x G operand (m | m)      ->  m m + h m
+//        Z operand (m | h) x G operand (h | h)      ->  m h + h h
+//    With the planes pre-split in LDS the pairing costs nothing: the two halves of a wave read different planes.
+//  * LDS plane: [16-feature block][slot(row)][32 bytes], slot = (row & 3) | row bit 3 << 2 | row bit 2 << 3, so the
+//    (rows q, 8 + q; 4 features each) gather of a transposed read is 256 contiguous bytes per half wave, the second
+//    read of a fragment sits +256 bytes, a feature block +512 bytes: every fragment address is one per-lane base
+//    plus an immediate.  The loader writes the same 256-byte runs (lane = block half, row slot, feature quad).
+//  * Z is the first MFMA operand: a 16 x 16 accumulator block holds, per lane, G feature (lane & 15) and four
+//    consecutive Z features -> 16-byte slab stores, re-paired to full 128-byte lines by two DPP moves per register.
+//  * 2 x 48 KB stage buffers, one workgroup per CU; tiles x splits = 256 workgroups for 512 x 512.
+// ---------------------------------------------------------------------------
+typedef float x3f32x4 __attribute__((ext_vector_type(4)));
+#define X3_MFMA16(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define X3T_PLANE (X3_TK * 512)                 // bytes of one 256-feature bf16 plane of a stage
+#define X3T_STAGE (6 * X3T_PLANE)               // G h, m, l then Z h, m, l
+
+// harness-only ablation switches (tools/build_tn_tune.sh; results wrong): 1 no global loads, 2 no split / LDS
+// stores, 4 no fragment reads, 8 no slab stores
+#ifdef WIRE_ABLATE_TN
+#define TN_ABL(x) ((abl & (x)) != 0)
+#define TN_ABL_PARAM , int abl
+#else
+#define TN_ABL(x) false
+#define TN_ABL_PARAM
+#endif
+
+__global__ __launch_bounds__(512, 2) void gemmx3_tn16_kernel(
+    const float* __restrict__ G, int ldg, const float* __restrict__ Z, int ldz, long long n, int Pm, int Pn,
+    int tiles_n, int nsplit, long long chunk, float* __restrict__ slab, float* __restrict__ bslab, int tiles
+    TN_ABL_PARAM) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave >> 1, wave_n = wave & 1;     // 64 features of G x 128 features of Z per wave
+  const int bb = blockIdx.x;
+  const int xcd = bb & 7, idx = bb >> 3;
+  const int tile = idx % tiles;
+  const int split = (idx / tiles) * 8 + xcd;
+  if (split >= nsplit) return;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m_base = tm * 256, n_base = tn * 256;
+  const long long row0 = (long long)split * chunk;
+  long long row1 = row0 + chunk;
+  if (row1 > n) row1 = n;
+  if (row1 <= row0) return;
+
+  // loader: wave w owns feature blocks 2w, 2w + 1 of both operands; a lane = (block half, row slot 0-7, quad p);
+  // pass t adds 4 to the row: rows {0-3, 8-11} then {4-7, 12-15}
+  const int l_fb = 2 * wave + (lane >> 5), l_rs = (lane >> 2) & 7, l_p = lane & 3;
+  const int l_row = (l_rs & 3) + 8 * (l_rs >> 2);
+  const int l_feat = 16 * l_fb + 4 * l_p;
+  const int l_st = l_fb * 512 + l_rs * 32 + l_p * 8;   // + 256 for pass 1
+  const bool do_bias = (bslab != nullptr) && (tn == 0);
+
+  x3f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = x3f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+  const int nrows = (int)(row1 - row0);
+  const int nk = (nrows + X3_TK - 1) / X3_TK;
+  const int nk_full = nrows / X3_TK;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  struct Staged { f32x4 g[2], z[2]; };
+  Staged st;
+  unsigned g_off[2], z_off[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    g_off[t] = (unsigned)(l_row + 4 * t) * (unsigned)ldg + (unsigned)(m_base + l_feat);
+    z_off[t] = (unsigned)(l_row + 4 * t) * (unsigned)ldz + (unsigned)(n_base + l_feat);
+  }
+  const float* const g_base = G + (size_t)row0 * ldg;
+  const float* const z_base = Z + (size_t)row0 * ldz;
+  auto gload = [&](Staged& R, int kt) {
+    int ks = kt < nk_full ? kt : nk_full - 1;
+    ks = ks < 0 ? 0 : ks;
+    const float* gb = g_base + (size_t)ks * (X3_TK * (size_t)ldg);
+    const float* zb = z_base + (size_t)ks * (X3_TK * (size_t)ldz);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) R.g[t] = *reinterpret_cast<const f32x4*>(gb + g_off[t]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) R.z[t] = *reinterpret_cast<const f32x4*>(zb + z_off[t]);
+  };
+  auto gload_tail = [&](Staged& R) {
+    const int rb = nk_full * X3_TK;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = rb + l_row + 4 * t;
+      R.g[t] = row < nrows ? *reinterpret_cast<const f32x4*>(g_base + (size_t)row * ldg + m_base + l_feat) : zero4;
+      R.z[t] = row < nrows ? *reinterpret_cast<const f32x4*>(z_base + (size_t)row * ldz + n_base + l_feat) : zero4;
+    }
+  };
+  auto lstore = [&](const Staged& R, int buf) {
+    unsigned char* S = smem_t + buf * X3T_STAGE + l_st;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const f32x4 gv = R.g[t];
+      const Split2 s0 = split2(gv[0], gv[1]), s1 = split2(gv[2], gv[3]);
+      unsigned char* d = S + t * 256;
+      *reinterpret_cast<u32x2*>(d) = u32x2{s0.h, s1.h};
+      *reinterpret_cast<u32x2*>(d + X3T_PLANE) = u32x2{s0.m, s1.m};
+      *reinterpret_cast<u32x2*>(d + 2 * X3T_PLANE) = u32x2{s0.l, s1.l};
+      if (do_bias) { bsum[0] += gv[0]; bsum[1] += gv[1]; bsum[2] += gv[2]; bsum[3] += gv[3]; }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const f32x4 zv = R.z[t];
+      const Split2 s0 = split2(zv[0], zv[1]), s1 = split2(zv[2], zv[3]);
+      unsigned char* d = S + 3 * X3T_PLANE + t * 256;
+      *reinterpret_cast<u32x2*>(d) = u32x2{s0.h, s1.h};
+      *reinterpret_cast<u32x2*>(d + X3T_PLANE) = u32x2{s0.m, s1.m};
+      *reinterpret_cast<u32x2*>(d + 2 * X3T_PLANE) = u32x2{s0.l, s1.l};
+    }
+  };
+
+  if (nk_full > 0) gload(st, 0); else gload_tail(st);
+  lstore(st, 0);
+  __syncthreads();
+
+  // fragment reads: 16-lane group g = lane >> 4 -> rows 8 (g & 1) + q, plane by g >> 1; the byte offset inside a
+  // feature block is (lane & 31) * 8 for the first read, + 256 for the second (rows + 4)
+  const int hi = lane >> 5;
+  const int r_lane = (lane & 31) * 8;
+  // plane order in LDS: 0 = h, 1 = m, 2 = l
+  const int g_lh = r_lane + (hi ? 0 : 2) * X3T_PLANE + wave_m * (4 * 512);          // G (l | h)
+  const int g_c = r_lane + wave_m * (4 * 512);                                       // G m / G h: + plane
+  const int z_hl = 3 * X3T_PLANE + r_lane + (hi ? 2 : 0) * X3T_PLANE + wave_n * (8 * 512);   // Z (h | l)
+  const int z_mh = 3 * X3T_PLANE + r_lane + (hi ? 0 : 1) * X3T_PLANE + wave_n * (8 * 512);   // Z (m | h)
+
+  auto frag = [&](const unsigned char* p) {
+    const s16x4 a = lds_tr16(p), b = lds_tr16(p + 256);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+
+  auto stage = [&](const int kt, const int mode) {
+    const int buf = kt & 1;
+    if (mode == 1 && !TN_ABL(1)) gload(st, kt + 1);
+    if (mode == 2) gload_tail(st);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const unsigned char* S = smem_t + buf * X3T_STAGE;
+      bf16x8 g1[4], g2[4], g3[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        g1[i] = frag(S + g_lh + i * 512);
+        g2[i] = frag(S + g_c + X3T_PLANE + i * 512);
+        g3[i] = frag(S + g_c + i * 512);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bf16x8 f1 = frag(S + z_hl + j * 512);
+        const bf16x8 f2 = frag(S + z_mh + j * 512);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          X3_MFMA16(f1, g1[i], acc[i][j]);
+          X3_MFMA16(f2, g2[i], acc[i][j]);
+          X3_MFMA16(f2, g3[i], acc[i][j]);
+        }
+      }
+    }
+    if (mode != 0 && !TN_ABL(2)) lstore(st, buf ^ 1);
+    __syncthreads();
+  };
+  int kt = 0;
+#ifdef WIRE_ABLATE_TN
+  if (TN_ABL(4)) {
+    // fragments read once, MFMAs on loop-invariant registers
+    const unsigned char* S = smem_t;
+    bf16x8 g1[4], g2[4], g3[4], f1[2], f2[2];
+    for (int i = 0; i < 4; ++i) { g1[i] = frag(S + g_lh + i * 512); g2[i] = frag(S + g_c + X3T_PLANE + i * 512); g3[i] = frag(S + g_c + i * 512); }
+    for (int j = 0; j < 2; ++j) { f1[j] = frag(S + z_hl + j * 512); f2[j] = frag(S + z_mh + j * 512); }
+    for (; kt + 1 < nk_full; ++kt) {
+      if (!TN_ABL(1)) gload(st, kt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          X3_MFMA16(f1[j & 1], g1[i], acc[i][j]);
+          X3_MFMA16(f2[j & 1], g2[i], acc[i][j]);
+          X3_MFMA16(f2[j & 1], g3[i], acc[i][j]);
+        }
+      if (!TN_ABL(2)) lstore(st, (kt & 1) ^ 1);
+      __syncthreads();
+    }
+  }
+#endif
+  for (; kt + 1 < nk_full; ++kt) stage(kt, 1);
+  if (nk_full > 0) { stage(kt, nk > nk_full ? 2 : 0); ++kt; }
+  if (nk > nk_full) stage(kt, 0);
+  if (TN_ABL(8)) return;
+
+  if (do_bias) {
+    // the 8 row-slot lanes of a feature quad: sum through LDS (all fragment reads are done)
+    float* red = reinterpret_cast<float*>(smem_t);
+    *reinterpret_cast<f32x4*>(&red[l_rs * 256 + l_feat]) = bsum;
+    __syncthreads();
+    if (tid < 256) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v += red[r * 256 + tid];
+      bslab[(size_t)split * Pm + m_base + tid] = v;
+    }
+  }
+  // accumulator block (i, j): lane -> G feature 16 i + (lane & 15), Z features 16 j + 4 (lane >> 4) + q.  Pair the
+  // blocks j, j + 1 inside each 16-lane row: lane (rr = lane & 7, ch = (lane >> 3) & 1, g = lane >> 4) then holds
+  // G feature rr (first result) / rr + 8 (second), Z features 32 (j / 2) + 16 ch + 4 g + q: whole 128-byte lines
+  float* out = slab + (size_t)split * Pm * Pn;
+  const int rr = lane & 7, cq = 16 * ((lane >> 3) & 1) + 4 * (lane >> 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m_base + wave_m * 64 + 16 * i + rr;
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+      x3f32x4 xp, yp;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int x = __float_as_int(acc[i][2 * jp][q]), y = __float_as_int(acc[i][2 * jp + 1][q]);
+        xp[q] = __int_as_float(__builtin_amdgcn_update_dpp(x, y, 0x128, 0xf, 0xc, false));
+        yp[q] = __int_as_float(__builtin_amdgcn_update_dpp(y, x, 0x128, 0xf, 0x3, false));
+      }
+      const int col = n_base + wave_n * 128 + 32 * jp + cq;
+      *reinterpret_cast<x3f32x4*>(out + (size_t)m * Pn + col) = xp;
+      *reinterpret_cast<x3f32x4*>(out + (size_t)(m + 8) * Pn + col) = yp;
+    }
+  }
+}
+
 // Row splits of the weight gradient: tiles x splits workgroups should fill the 256 CUs of an MI355X with the
 // SAME number of resident workgroups each (3, else 2, else 1) -- e.g. K = 181 (9 tiles): 56 splits = 504
 // workgroups = 2 per CU, where 64 splits (576 workgroups) would leave a quarter of the CUs with 3 and the
 // rest with 2, and the launch waits for the loaded ones.
-int gemmx3_tn_splits(int64_t n, int Pm, int Pn, int max_splits) {
-  const int tiles = ((Pm + 127) / 128) * ((Pn + 127) / 128);
+// a single 256 x 256 tile (siren / gauss / relu at 256 features) cannot fill the chip within the split cap and
+// measured 0 - 2 % slower than the 128 x 128 kernel: two tiles or more
+static bool tn16_applies(int Pm, int Pn, int mode) {
+  return mode != 0 && Pm % 256 == 0 && Pn % 256 == 0 && (Pm / 256) * (Pn / 256) >= 2;
+}
+
+static int tn_splits_for(int64_t n, int Pm, int Pn, int max_splits, bool tn16) {
   int s = 0;
-  for (int w = 3; w >= 1 && s == 0; --w) {
-    const int c = (256 * w) / tiles;
-    if (c >= 1 && c <= max_splits) s = c;
+  if (tn16) {
+    // 256 x 256 tiles, one 8-wave workgroup per CU
+    const int tiles = (Pm / 256) * (Pn / 256);
+    s = tiles >= 256 ? 1 : 256 / tiles;
+  } else {
+    const int tiles = ((Pm + 127) / 128) * ((Pn + 127) / 128);
+    for (int w = 3; w >= 1 && s == 0; --w) {
+      const int c = (256 * w) / tiles;
+      if (c >= 1 && c <= max_splits) s = c;
+    }
+    if (s == 0) s = tiles > 768 ? 1 : max_splits;   // the tiles alone fill the chip / fewer tiles than the cap allows
   }
-  if (s == 0) s = tiles > 768 ? 1 : max_splits;   // the tiles alone fill the chip / fewer tiles than the cap allows
   int64_t by_rows = (n + 255) / 256;          // at least 256 rows per split
   if (by_rows < 1) by_rows = 1;
   if (s > by_rows) s = (int)by_rows;
@@ -667,13 +924,24 @@ int gemmx3_tn_splits(int64_t n, int Pm, int Pn, int max_splits) {
   s = (int)((n + chunk - 1) / chunk);
   return s < 1 ? 1 : s;
 }
+int gemmx3_tn_splits(int64_t n, int Pm, int Pn, int max_splits) {
+  return tn_splits_for(n, Pm, Pn, max_splits, tn16_applies(Pm, Pn, g_x3_tn16));
+}
+// the larger of the two kernels' counts: scratch sized with it stays valid when "x3_tn16" is switched
+int gemmx3_tn_splits_max(int64_t n, int Pm, int Pn, int max_splits) {
+  const int a = tn_splits_for(n, Pm, Pn, max_splits, false);
+  const int b = tn16_applies(Pm, Pn, 1) ? tn_splits_for(n, Pm, Pn, max_splits, true) : a;
+  return a > b ? a : b;
+}
 
 hipError_t launch_gemmx3_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n,
                             int Pm, int Pn, int splits, float* slab, float* bslab) {
   // all padded widths are multiples of 64; a ragged last tile clamps its loader column inside the row
   if ((Pm & 63) || (Pn & 63) || (ldg & 3) || (ldz & 3) || splits < 1 || n < 1) return hipErrorInvalidValue;
-  const bool tall = g_x3_tn_tall && (Pm % 256 == 0);
-  const int tiles_m = tall ? Pm / 256 : (Pm + 127) / 128, tiles_n = (Pn + 127) / 128;
+  const bool tn16 = tn16_applies(Pm, Pn, g_x3_tn16);
+  const bool tall = !tn16 && g_x3_tn_tall && (Pm % 256 == 0);
+  const int tiles_m = tn16 || tall ? Pm / 256 : (Pm + 127) / 128;
+  const int tiles_n = tn16 ? Pn / 256 : (Pn + 127) / 128;
   long long chunk = (n + splits - 1) / splits;
   chunk = (chunk + 2 * X3_TK - 1) / (2 * X3_TK) * (2 * X3_TK);
   // no empty split: shrink the count to what the rounded chunk needs
@@ -689,7 +957,19 @@ hipError_t launch_gemmx3_tn(hipStream_t s, const float* G, int ldg, const float*
       if (e != hipSuccess) return e;
     }
   }
-  if (tall)
+  if (tn16) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemmx3_tn16_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * X3T_STAGE);
+    if (attr != hipSuccess) return attr;
+#ifdef WIRE_ABLATE_TN
+    static const int abl = x3_env("WIRE_TN_ABL", 0);
+    hipLaunchKernelGGL(gemmx3_tn16_kernel, grid, dim3(512), 2 * X3T_STAGE, s, G, ldg, Z, ldz, (long long)n, Pm, Pn,
+                       tiles_n, used, chunk, slab, bslab, tiles_m * tiles_n, abl);
+#else
+    hipLaunchKernelGGL(gemmx3_tn16_kernel, grid, dim3(512), 2 * X3T_STAGE, s, G, ldg, Z, ldz, (long long)n, Pm, Pn,
+                       tiles_n, used, chunk, slab, bslab, tiles_m * tiles_n);
+#endif
+  } else if (tall)
     hipLaunchKernelGGL(gemmx3_tn_kernel<4>, grid, dim3(256), 0, s, G, ldg, Z, ldz, (long long)n, Pm, Pn, tiles_n,
                        used, chunk, slab, bslab, tiles_m * tiles_n);
   else
