@@ -105,9 +105,9 @@ int main(int argc, char** argv) {
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       if (r > 0) tsum[mode] += ms / 4;
     }
+  const char* names[2] = {"tn   128x128 32x32x16", "tn16 256x256 16x16x32"};
   for (int mode = 0; mode < 2; ++mode)
-    printf("  %-28s mean %7.3f ms  (%d row splits)  -> %6.1f alg TF  frac %.3f\n",
-           mode ? "tn16 256x256 16x16x32" : "tn   128x128 32x32x16", tsum[mode] / rounds, Ss[mode],
+    printf("  %-28s mean %7.3f ms  (%d row splits)  -> %6.1f alg TF  frac %.3f\n", names[mode], tsum[mode] / rounds, Ss[mode],
            flop / (tsum[mode] / rounds * 1e-3) / 1e12, flop / (tsum[mode] / rounds * 1e-3) / 1e12 / 416.7);
   return 0;
 }

@@ -774,10 +774,6 @@ __global__ __launch_bounds__(512, 2) void gemmx3_tn16_kernel(
     }
   };
 
-  if (nk_full > 0) gload(st, 0); else gload_tail(st);
-  lstore(st, 0);
-  __syncthreads();
-
   // fragment reads: 16-lane group g = lane >> 4 -> rows 8 (g & 1) + q, plane by g >> 1; the byte offset inside a
   // feature block is (lane & 31) * 8 for the first read, + 256 for the second (rows + 4)
   const int hi = lane >> 5;
@@ -793,33 +789,57 @@ __global__ __launch_bounds__(512, 2) void gemmx3_tn16_kernel(
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
   };
 
-  auto stage = [&](const int kt, const int mode) {
-    const int buf = kt & 1;
-    if (mode == 1 && !TN_ABL(1)) gload(st, kt + 1);
-    if (mode == 2) gload_tail(st);
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      const unsigned char* S = smem_t + buf * X3T_STAGE;
-      bf16x8 g1[4], g2[4], g3[4];
+  auto mfma_block = [&](const int buf) {
+    const unsigned char* S = smem_t + buf * X3T_STAGE;
+    bf16x8 g1[4], g2[4], g3[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      g1[i] = frag(S + g_lh + i * 512);
+      g2[i] = frag(S + g_c + X3T_PLANE + i * 512);
+      g3[i] = frag(S + g_c + i * 512);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bf16x8 f1 = frag(S + z_hl + j * 512);
+      const bf16x8 f2 = frag(S + z_mh + j * 512);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        g1[i] = frag(S + g_lh + i * 512);
-        g2[i] = frag(S + g_c + X3T_PLANE + i * 512);
-        g3[i] = frag(S + g_c + i * 512);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const bf16x8 f1 = frag(S + z_hl + j * 512);
-        const bf16x8 f2 = frag(S + z_mh + j * 512);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          X3_MFMA16(f1, g1[i], acc[i][j]);
-          X3_MFMA16(f2, g2[i], acc[i][j]);
-          X3_MFMA16(f2, g3[i], acc[i][j]);
-        }
+        X3_MFMA16(f1, g1[i], acc[i][j]);
+        X3_MFMA16(f2, g2[i], acc[i][j]);
+        X3_MFMA16(f2, g3[i], acc[i][j]);
       }
     }
-    if (mode != 0 && !TN_ABL(2)) lstore(st, buf ^ 1);
+  };
+  // stage s of the split into the staging registers: a full stage, the ragged tail, or nothing
+  auto load_any = [&](const int sidx) {
+    if (sidx < nk_full) gload(st, sidx);
+    else if (sidx < nk) gload_tail(st);
+  };
+  // Two wave kinds, so that the two waves of a SIMD (w and w + 4) are out of phase between the barriers -- one runs
+  // its MFMAs while the other splits and stores (all waves in phase: 0.69 ms; all early: 0.66; odd waves early, i.e.
+  // whole SIMDs in phase: 0.65; this: 0.60 -- profiles/r02b_gemm_tn16_ab.txt):
+  //   late  (waves 0-3): loads of stage kt + 1 | MFMAs of stage kt | split + store stage kt + 1
+  //   early (waves 4-7): split + store stage kt + 1 (loaded a stage ago) | loads of stage kt + 2 | MFMAs of stage kt
+  // Both write buffer (kt + 1) & 1 during stage kt and read buffer kt & 1: the buffer protocol is the same.
+  const bool early = wave >= 4;
+  load_any(0);
+  lstore(st, 0);
+  if (early) load_any(1);
+  __syncthreads();
+
+  auto stage = [&](const int kt, const bool fast) {
+    const int buf = kt & 1;
+    if (!early) {
+      if (fast) { if (!TN_ABL(1)) gload(st, kt + 1); } else load_any(kt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(buf);
+      if ((fast || kt + 1 < nk) && !TN_ABL(2)) lstore(st, buf ^ 1);
+    } else {
+      if ((fast || kt + 1 < nk) && !TN_ABL(2)) lstore(st, buf ^ 1);
+      if (fast) { if (!TN_ABL(1)) gload(st, kt + 2); } else load_any(kt + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(buf);
+    }
     __syncthreads();
   };
   int kt = 0;
@@ -830,7 +850,7 @@ __global__ __launch_bounds__(512, 2) void gemmx3_tn16_kernel(
     bf16x8 g1[4], g2[4], g3[4], f1[2], f2[2];
     for (int i = 0; i < 4; ++i) { g1[i] = frag(S + g_lh + i * 512); g2[i] = frag(S + g_c + X3T_PLANE + i * 512); g3[i] = frag(S + g_c + i * 512); }
     for (int j = 0; j < 2; ++j) { f1[j] = frag(S + z_hl + j * 512); f2[j] = frag(S + z_mh + j * 512); }
-    for (; kt + 1 < nk_full; ++kt) {
+    for (; kt + 2 < nk_full; ++kt) {
       if (!TN_ABL(1)) gload(st, kt + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -846,9 +866,8 @@ __global__ __launch_bounds__(512, 2) void gemmx3_tn16_kernel(
     }
   }
 #endif
-  for (; kt + 1 < nk_full; ++kt) stage(kt, 1);
-  if (nk_full > 0) { stage(kt, nk > nk_full ? 2 : 0); ++kt; }
-  if (nk > nk_full) stage(kt, 0);
+  for (; kt + 2 < nk_full; ++kt) stage(kt, true);      // stages kt + 1 and kt + 2 are full ones
+  for (; kt < nk; ++kt) stage(kt, false);
   if (TN_ABL(8)) return;
 
   if (do_bias) {
