@@ -278,6 +278,9 @@ int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* 
  *     bit 0 wire forward, bit 1 wire data gradient, bit 2 siren / gauss / relu, bit 3 wire2d; 0 = the 32x32x16 kernels.
  * "x3_tn16" (default 1): the weight-gradient (TN) GEMM of the split-bf16 family runs its 256 x 256-tile
  *     v_mfma_f32_16x16x32_bf16 kernel when both padded widths are multiples of 256; 0 = the 128 x 128 kernel.
+ * "recompute_out" (default 1): on the 16x16x32 kernels the backward of a wire net evaluates out = act(lin) again
+ *     (same lean form, same bits) instead of reading it back: data-gradient epilogues, the fused final stage of
+ *     wire_train_fwd_bwd (whose last hidden layer then does not store out at all).  0 = read the stored activations.
  * "x3_glds" (default 0): 1 / 2 = LDS-DMA 32x32x16 editions of the split-bf16 NT GEMM at M >= 4096
  *     (wire_gemmx3g.hip).  All editions give bit-identical GEMM results.
  * Neither buffer sizes (wire_packed_floats, wire_act_bytes, wire_bwd_scratch_bytes) nor
@@ -285,7 +288,7 @@ int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* 
  * family, activations are fp32 blocked rows for all of them, so a knob may change between
  * a forward and its backward.                                                  */
 int wire_tune_set(const char* key, int value);
-int wire_tune_get(const char* key);   /* "split_bf16" | "complex_3m" | "x3_h16" | "x3_tn16" -> value; < 0 = error */
+int wire_tune_get(const char* key);   /* "split_bf16" | "complex_3m" | "x3_h16" | "x3_tn16" | "recompute_out" -> value; < 0 = error */
 
 /* ---- profiling hooks (bench.py roofline) -------------------------------
  * When enabled, every launch of the hot kernels is bracketed by hipEvents on

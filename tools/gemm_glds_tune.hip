@@ -83,6 +83,7 @@ int main(int argc, char** argv) {
   std::vector<Var> vars = {
       {"x3h 16x16x32 store", 10, EPI_STORE, 0}, {"x3h 16x16x32 gabor_fwd", 10, EPI_GABOR_FWD, 0},
       {"x3h 16x16x32 gabor_bwd", 10, EPI_GABOR_BWD, 0},
+      {"x3h gabor_bwd recompute out", 10, EPI_GABOR_BWD, -100},
       {"x3h fwd stagger 15us", 10, EPI_GABOR_FWD, 1500}, {"x3h fwd stagger 30us", 10, EPI_GABOR_FWD, 3000},
       {"x3h bwd stagger 15us", 10, EPI_GABOR_BWD, 1500}, {"x3h bwd stagger 30us", 10, EPI_GABOR_BWD, 3000},
       {"x3h store stagger 30us", 10, EPI_STORE, 3000},
@@ -109,9 +110,10 @@ int main(int argc, char** argv) {
       GemmEpiParams ep;
       ep.bias = bias; ep.o0 = o0; ep.o1 = o1; ep.i0 = lin; ep.i1 = out; ep.ld0 = P; ep.ld1 = P;
       ep.omega = 20.f; ep.scale = 30.f; ep.kvalid = P / 2;
+      if (V.stagger == -100) ep.recompute_out = 1;     // data gradient that recomputes out from lin
       gemmx3g_tune_set("x3_glds", V.mode == 10 ? 0 : V.mode);
       gemmx3h_tune_set("x3_h16", V.mode == 10 ? 3 : 0);
-      gemmx3h_tune_set("x3h_stagger", V.mode == 10 ? V.stagger : 0);
+      gemmx3h_tune_set("x3h_stagger", V.mode == 10 && V.stagger > 0 ? V.stagger : 0);
       gemmx3g_tune_set("x3_stagger", V.stagger > 0 ? V.stagger : 0);
       gemmx3g_tune_set("x3_stagger_lo", V.stagger < 0 ? -V.stagger : 256);
       CK(hipEventRecord(e0, 0));

@@ -98,6 +98,9 @@ extern "C" int wire_prof_read(double* ms_total, int64_t* launches, double* flops
 // ---------------------------------------------------------------------------
 // tuning knobs
 // ---------------------------------------------------------------------------
+// wire training step on the 16 x 16 x 32 kernels: backward passes evaluate out = act(lin) again instead of reading it
+// (the data-gradient epilogues and the fused final stage), and the last hidden layer does not store out at all
+static int g_recompute_out = [] { const char* v = getenv("WIRE_RECOMPUTE_OUT"); return v ? atoi(v) : 1; }();
 static int g_complex_3m = 1;   // wire: 3-multiplication complex GEMMs on the fp32 MFMA (wire_gemm3m.hip)
 static int env_flag(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -116,12 +119,14 @@ extern "C" int wire_tune_get(const char* key) {
   if (!strcmp(key, "split_bf16")) return g_split_bf16;
   if (!strcmp(key, "x3_h16")) return gemmx3h_mode();
   if (!strcmp(key, "x3_tn16")) return gemmx3_tn16_mode();
+  if (!strcmp(key, "recompute_out")) return g_recompute_out;
   return fail(WIRE_ERR_ARG, "unknown tuning key: %s", key);
 }
 extern "C" int wire_tune_set(const char* key, int value) {
   if (!key) return fail(WIRE_ERR_ARG, "null key");
   if (!strcmp(key, "complex_3m")) { g_complex_3m = value ? 1 : 0; return WIRE_OK; }
   if (!strcmp(key, "split_bf16")) { g_split_bf16 = value ? 1 : 0; return WIRE_OK; }
+  if (!strcmp(key, "recompute_out")) { g_recompute_out = value ? 1 : 0; return WIRE_OK; }
   if (gemm_tune_set(key, value) == 0) return WIRE_OK;
   if (gemmx3_tune_set(key, value) == 0) return WIRE_OK;
   return fail(WIRE_ERR_ARG, "unknown tuning key or bad value: %s=%d", key, value);
@@ -361,7 +366,8 @@ extern "C" int wire_pack_params(void* stream, const wire_net_desc* d, const void
 // whole-network forward
 // ---------------------------------------------------------------------------
 static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const float* coords, int64_t n,
-                        float* y, void* act, int64_t act_bytes, int save_for_bwd, bool do_final) {
+                        float* y, void* act, int64_t act_bytes, int save_for_bwd, bool do_final,
+                        bool skip_last_out = false) {
   if (n < 0) return fail(WIRE_ERR_ARG, "negative n");
   if (n == 0) return WIRE_OK;
   if (!packed || !coords || (do_final && !y) || !act) return fail(WIRE_ERR_ARG, "null pointer");
@@ -403,6 +409,7 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
   for (int l = 1; l <= p.L; ++l) {
     GemmEpiParams ep; ep.bias = packed + p.off_bias[l]; ep.o0 = lin_l(l); ep.o1 = out_l(l);
     ep.ld0 = p.Pl; ep.ld1 = p.P; ep.omega = p.w; ep.scale = p.s; ep.kvalid = p.K;
+    if (skip_last_out && l == p.L) ep.o1 = nullptr;       // wire_train_fwd_bwd: the final stage recomputes it
     ProfScope ps(s, 0, 2.0 * n * p.Pl * p.P);
     if (p.m3)
       HIPCHK(launch_gemm3m_nt(s, EPI_GABOR_FWD, out_l(l - 1), p.P, packed + p.off_fwd_3m[l], p.P, n, p.Kp,
@@ -520,6 +527,8 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
       epi = epi_bwd(p.kind);
       ep.omega = (l - 1 == 0) ? p.w1 : p.w;
       ep.i0 = lin_l(l - 1); ep.o0 = gnext; ep.ld0 = p.Pl;
+      // hidden Gabor layer whose forward ran the lean 16 x 16 x 32 epilogue: out = act(lin) again, 8 B / element less
+      ep.recompute_out = g_recompute_out && p.x3 && p.kind == WIRE_KIND_WIRE && gemmx3_nt_is_h16(EPI_GABOR_FWD, n);
     } else {
       epi = (p.kind == WIRE_KIND_WIRE) ? EPI_GABOR_BWD_FIRST : EPI_GABOR2D_BWD_FIRST;
       ep.omega = p.w1;
@@ -598,7 +607,10 @@ extern "C" int wire_train_fwd_bwd(void* stream, const wire_net_desc* d, const fl
       HIPCHK(launch_mse_grad(s, y, target, idx, first, n, p.O, weight, g_y, loss_out, rec, partial)); }
     return mlp_bwd_core(stream, p, packed, coords, n, g_y, act, act_bytes, scratch, scratch_bytes, grads, true);
   }
-  if (int rc = mlp_fwd_core(stream, p, packed, coords, n, nullptr, act, act_bytes, 1, false)) return rc;
+  // with layer L on the 16 x 16 x 32 forward kernel (lean epilogue) the final stage evaluates out_L from lin_L itself,
+  // bit for bit what that epilogue would have stored: out_L is neither written nor read (1 GB less HBM traffic)
+  const bool recomp = g_recompute_out && p.x3 && gemmx3_nt_is_h16(EPI_GABOR_FWD, n);
+  if (int rc = mlp_fwd_core(stream, p, packed, coords, n, nullptr, act, act_bytes, 1, false, recomp)) return rc;
   const ActLayout a = act_layout(p, n, 1);
   const ScratchLayout sc = scratch_layout(p, n);
   if (scratch_bytes < sc.total * 4) return fail(WIRE_ERR_SIZE, "scratch too small");
@@ -608,8 +620,8 @@ extern "C" int wire_train_fwd_bwd(void* stream, const wire_net_desc* d, const fl
     // final linear forward + MSE (loss, rec) + final linear backward + Gabor gradient of layer L:
     // one pass over out_L / lin_L instead of three
     ProfScope ps(s, 3, 0);
-    HIPCHK(launch_final_fused(s, A + a.out0 + (int64_t)p.L * n * p.P, A + a.lin1 + (int64_t)(p.L - 1) * n * p.Pl,
-                              n, p.P, p.O, packed + p.off_wf, packed + p.off_bf, target, idx, first, weight,
+    HIPCHK(launch_final_fused(s, recomp ? nullptr : A + a.out0 + (int64_t)p.L * n * p.P,
+                              A + a.lin1 + (int64_t)(p.L - 1) * n * p.Pl, n, p.P, p.O, p.K, packed + p.off_wf, packed + p.off_bf, target, idx, first, weight,
                               p.w, p.s, y, rec, Sx + sc.ga, Sx + sc.fpw, Sx + sc.fpb, Sx + sc.crp, loss_out));
   }
   return mlp_bwd_core(stream, p, packed, coords, n, nullptr, act, act_bytes, scratch, scratch_bytes, grads, false);

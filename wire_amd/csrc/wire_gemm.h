@@ -35,6 +35,7 @@ struct GemmEpiParams {
   int D = 0;
   int ldu = 0;
   int wide = 0;                  // set by the launcher when 32-bit byte offsets could overflow
+  int recompute_out = 0;         // EPI_GABOR_BWD of wire_gemmx3h.hip: out = act(lin) again instead of reading i1
   int stagger = 0, stagger_lo = 0, stagger_hi = 0;   // wire_gemmx3g.hip: late start (100 MHz ticks) of blocks [lo, hi)
 #ifdef WIRE_ABLATE
   int ablate = 0;                // tools/gemm_tune only: 1 no global loads, 2 no LDS writes, 4 no barrier
@@ -74,6 +75,7 @@ hipError_t launch_x3_split_b(hipStream_t s, const float* Bt, int ldb, int Nc, in
 hipError_t launch_gemmx3_nt(hipStream_t s, int epi, const float* A, int lda, const void* Bx3, int64_t M,
                             int Nc, int Kd, const GemmEpiParams& ep);
 int gemmx3_tune_set(const char* key, int value);
+bool gemmx3_nt_is_h16(int epi, int64_t M);
 int gemmx3_tn16_mode();
 int gemmx3_tn_splits(int64_t n, int Pm, int Pn, int max_splits);
 int gemmx3_tn_splits_max(int64_t n, int Pm, int Pn, int max_splits);   // over the "x3_tn16" settings (scratch sizing)

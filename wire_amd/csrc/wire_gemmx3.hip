@@ -367,6 +367,10 @@ int gemmx3_tune_set(const char* key, int value) {
   return gemmx3g_tune_set(key, value);
 }
 
+// true when launch_gemmx3_nt runs this epilogue on the 16 x 16 x 32 edition (lean epilogues, optional out store,
+// recompute_out) at M rows under the current knobs
+bool gemmx3_nt_is_h16(int epi, int64_t M) { return !gemmx3g_handles(epi, M) && gemmx3h_handles(epi, M); }
+
 hipError_t launch_gemmx3_nt(hipStream_t s, int epi, const float* A, int lda, const void* Bx3, int64_t M,
                             int Nc, int Kd, const GemmEpiParams& ep_in) {
   if (M <= 0) return hipSuccess;

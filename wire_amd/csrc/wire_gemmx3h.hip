@@ -347,29 +347,37 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
 #pragma unroll
           for (int hr = 0; hr < 2; ++hr) {
             const int row = m_w + 16 * rb + 8 * hr + rr;
-            f32x4 u, v, o_re, o_im;
+            f32x4 u, v;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               u[q] = are[hr][q] + b_re[q];
               v[q] = aim[hr][q] + b_im[q];
-              float a, b;
-              gabor_fwd_lean(u[q], v[q], w0, w0l2e, ns2l2e, a, b);
-              const bool valid = f0 + q < ep.kvalid;               // pad features are written as 0
-              o_re[q] = valid ? a : 0.f;
-              o_im[q] = valid ? b : 0.f;
             }
-            if (row < M) {
-              if (ep.o0) {
-                float* Lp = ep.o0 + (size_t)row * ep.ld0 + c0;
-                *reinterpret_cast<f32x4*>(Lp) = u;
-                *reinterpret_cast<f32x4*>(Lp + 32) = v;
+            if (ep.o0 && row < M) {
+              float* Lp = ep.o0 + (size_t)row * ep.ld0 + c0;
+              *reinterpret_cast<f32x4*>(Lp) = u;
+              *reinterpret_cast<f32x4*>(Lp + 32) = v;
+            }
+            // o1 = null: the last hidden layer of a fused training step -- the final stage recomputes out from lin
+            if (ep.o1) {
+              f32x4 o_re, o_im;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                float a, b;
+                gabor_fwd_lean(u[q], v[q], w0, w0l2e, ns2l2e, a, b);
+                const bool valid = f0 + q < ep.kvalid;             // pad features are written as 0
+                o_re[q] = valid ? a : 0.f;
+                o_im[q] = valid ? b : 0.f;
               }
-              float* Op = ep.o1 + (size_t)row * ep.ld1 + c0;
-              *reinterpret_cast<f32x4*>(Op) = o_re;
-              *reinterpret_cast<f32x4*>(Op + 32) = o_im;
+              if (row < M) {
+                float* Op = ep.o1 + (size_t)row * ep.ld1 + c0;
+                *reinterpret_cast<f32x4*>(Op) = o_re;
+                *reinterpret_cast<f32x4*>(Op + 32) = o_im;
+              }
             }
           }
         } else if constexpr (EPI == EPI_GABOR_BWD) {
+          const bool recompute = ep.recompute_out != 0;
           f32x4 lu[2], lv[2], pr[2], pi[2];
 #pragma unroll
           for (int hr = 0; hr < 2; ++hr) {                          // all 8 loads of the row block first
@@ -379,8 +387,24 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
             const float* Op = ep.i1 + (size_t)row * ep.ld1 + c0;
             lu[hr] = *reinterpret_cast<const f32x4*>(Lp);
             lv[hr] = *reinterpret_cast<const f32x4*>(Lp + 32);
-            pr[hr] = *reinterpret_cast<const f32x4*>(Op);
-            pi[hr] = *reinterpret_cast<const f32x4*>(Op + 32);
+            if (!recompute) {
+              pr[hr] = *reinterpret_cast<const f32x4*>(Op);
+              pi[hr] = *reinterpret_cast<const f32x4*>(Op + 32);
+            }
+          }
+          if (recompute) {
+            // out = act(lin) again instead of 8 more bytes per element from HBM: the same lean form as the forward
+            // epilogue above, so the value equals the stored one bit for bit when that epilogue produced it
+#pragma unroll
+            for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                float a, b;
+                gabor_fwd_lean(lu[hr][q], lv[hr][q], w0, w0l2e, ns2l2e, a, b);
+                const bool valid = f0 + q < ep.kvalid;
+                pr[hr][q] = valid ? a : 0.f;
+                pi[hr][q] = valid ? b : 0.f;
+              }
           }
 #pragma unroll
           for (int hr = 0; hr < 2; ++hr) {

@@ -390,14 +390,22 @@ __global__ void mse_final_kernel(const float* __restrict__ partial, int nb, floa
                                  float* __restrict__ loss_out);
 // (the kernel keeps 4 O P floats of W_f / partial sums in dynamic LDS: it must fit the 64 KB a launch gets
 // without an opt-in -- O = 4 with P = 1024 does not, and runs the unfused sequence instead)
+// dynamic LDS of the fused final stage: [4 waves][O][P] g_wf partials, [4][FF_MAXO + 1] bias / loss partials, then the
+// block's gathered targets [FB_ROWS][FF_MAXO] and source indices [FB_ROWS] (int64)
+static size_t final_fused_shm(int P, int O) {
+  return ((size_t)4 * O * P + 4 * (FF_MAXO + 1) + (size_t)FB_ROWS * FF_MAXO) * sizeof(float) + (size_t)FB_ROWS * 8;
+}
 bool final_fused_supported(int P, int O) {
-  return (P % 64) == 0 && P <= 512 * FF_MAXPASS && O <= FF_MAXO &&
-         ((size_t)4 * O * P + 4 * (FF_MAXO + 1)) * sizeof(float) <= 65536;
+  return (P % 64) == 0 && P <= 512 * FF_MAXPASS && O <= FF_MAXO && final_fused_shm(P, O) <= 65536;
 }
 
-template <int NPASS>
+// RECOMP: out_L is not read -- it is evaluated again from lin_L with the lean forward form (bit-identical to what the
+// 16 x 16 x 32 forward epilogue would have stored; wire_api.hip selects this only when that kernel ran layer L, and
+// then does not let it write out_L at all): 1 GB instead of 1.5 GB of HBM traffic for this pass.
+// OT = O (1..FF_MAXO): the weight / partial-sum registers are sized for the actual number of outputs
+template <int NPASS, bool RECOMP, int OT>
 __global__ __launch_bounds__(256) void final_fused_kernel(
-    const float* __restrict__ out, const float* __restrict__ lin, long long n, int P, int O,
+    const float* __restrict__ out, const float* __restrict__ lin, long long n, int P, int O, int kvalid,
     const float* __restrict__ wf, const float* __restrict__ bfr, const float* __restrict__ target,
     const int64_t* __restrict__ idx, long long first, float gscale, float omega, float scale,
     float* __restrict__ y, float* __restrict__ rec, float* __restrict__ g_lin, float* __restrict__ part_w,
@@ -413,15 +421,15 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
   // this lane's columns and weights
   int col[NPASS];
   bool live[NPASS];
-  f32x4 wre[NPASS][FF_MAXO], wim[NPASS][FF_MAXO];
-  f32x4 are[NPASS][FF_MAXO], aim[NPASS][FF_MAXO];
+  f32x4 wre[NPASS][OT], wim[NPASS][OT];
+  f32x4 are[NPASS][OT], aim[NPASS][OT];
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
     const int g = (lane >> 3) + 8 * ps;
     live[ps] = g < ngrp;
     col[ps] = (g << 6) + 4 * (lane & 7);
 #pragma unroll
-    for (int o = 0; o < FF_MAXO; ++o) {
+    for (int o = 0; o < OT; ++o) {
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
       wre[ps][o] = z4; wim[ps][o] = z4; are[ps][o] = z4; aim[ps][o] = z4;
       if (live[ps] && o < O) {
@@ -430,35 +438,67 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
       }
     }
   }
-  float bsum[FF_MAXO] = {0.f, 0.f, 0.f, 0.f};
+  float bsum[OT];
+#pragma unroll
+  for (int o = 0; o < OT; ++o) bsum[o] = 0.f;
   float lsum = 0.f;
 
-  // software pipeline over this wave's rows: the loads of row r+4 are in flight while row r goes
-  // through its butterfly / gradient chain (one row alone keeps only 4 KB per wave in flight)
-  f32x4 nzr[NPASS], nzi[NPASS], nlr[NPASS], nli[NPASS];
-  auto load_row = [&](long long row) {
+  // the block's source indices and targets, gathered once by all 256 threads: inside the row loop the chain
+  // idx[row] -> target[src] would be two dependent global loads per row and wave (it bounded the pass)
+  float* s_tg = sm + (size_t)4 * O * P + 4 * (FF_MAXO + 1);                       // [FB_ROWS][FF_MAXO]
+  long long* s_src = reinterpret_cast<long long*>(s_tg + FB_ROWS * FF_MAXO);      // [FB_ROWS]
+  {
+    const long long grow = r0 + threadIdx.x;
+    if (grow < r1) {
+      const long long src = idx ? idx[grow] : first + grow;
+      s_src[threadIdx.x] = src;
+#pragma unroll
+      for (int o = 0; o < OT; ++o) s_tg[threadIdx.x * FF_MAXO + o] = target[src * O + o];
+    }
+  }
+  __syncthreads();
+
+  // software pipeline over this wave's rows: the loads of the next PF rows of this wave (r + 4, r + 8, ...) are in
+  // flight while row r goes through its butterfly / gradient chain -- the pass is bound by memory latency, and one
+  // row is only 4 KB (2 KB when out is recomputed) per wave in flight
+  constexpr int PF = RECOMP ? 3 : 2;
+  f32x4 nzr[PF][NPASS], nzi[PF][NPASS], nlr[PF][NPASS], nli[PF][NPASS];
+  auto load_row = [&](const int slot, long long row) {
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-      nzr[ps] = z4; nzi[ps] = z4; nlr[ps] = z4; nli[ps] = z4;
+      nzr[slot][ps] = z4; nzi[slot][ps] = z4; nlr[slot][ps] = z4; nli[slot][ps] = z4;
       if (live[ps] && row < r1) {
         const size_t o_ = (size_t)row * P + col[ps];
-        nzr[ps] = *reinterpret_cast<const f32x4*>(out + o_);
-        nzi[ps] = *reinterpret_cast<const f32x4*>(out + o_ + 32);
-        nlr[ps] = *reinterpret_cast<const f32x4*>(lin + o_);
-        nli[ps] = *reinterpret_cast<const f32x4*>(lin + o_ + 32);
+        if (!RECOMP) {
+          nzr[slot][ps] = *reinterpret_cast<const f32x4*>(out + o_);
+          nzi[slot][ps] = *reinterpret_cast<const f32x4*>(out + o_ + 32);
+        }
+        nlr[slot][ps] = *reinterpret_cast<const f32x4*>(lin + o_);
+        nli[slot][ps] = *reinterpret_cast<const f32x4*>(lin + o_ + 32);
       }
     }
   };
-  load_row(r0 + wave);
-  for (long long row = r0 + wave; row < r1; row += 4) {
-    f32x4 zr[NPASS], zi[NPASS], lr[NPASS], li[NPASS];
+  auto process = [&](const long long row, f32x4 (&zr)[NPASS], f32x4 (&zi)[NPASS], const f32x4 (&lr)[NPASS],
+                     const f32x4 (&li)[NPASS]) {
+    if (RECOMP) {
+      const float w0l2e = omega * 1.44269502f, ns2l2e = -(scale * scale) * 1.44269502f;
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) { zr[ps] = nzr[ps]; zi[ps] = nzi[ps]; lr[ps] = nlr[ps]; li[ps] = nli[ps]; }
-    load_row(row + 4);
-    float yo[FF_MAXO];
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int f0 = ((col[ps] >> 6) << 5) + (col[ps] & 31);     // features f0 .. f0 + 3 of this lane
 #pragma unroll
-    for (int o = 0; o < FF_MAXO; ++o) {
+        for (int j = 0; j < 4; ++j) {
+          float a_, b_;
+          gabor_fwd_lean(lr[ps][j], li[ps][j], omega, w0l2e, ns2l2e, a_, b_);
+          const bool valid = live[ps] && f0 + j < kvalid;          // pad features are 0
+          zr[ps][j] = valid ? a_ : 0.f;
+          zi[ps][j] = valid ? b_ : 0.f;
+        }
+      }
+    }
+    float yo[OT];
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
       float acc = 0.f;
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps)
@@ -468,19 +508,20 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
       yo[o] = acc;
     }
 #pragma unroll
-    for (int o = 0; o < FF_MAXO; ++o)
+    for (int o = 0; o < OT; ++o)
       if (o < O) {
 #pragma unroll
         for (int sft = 32; sft >= 1; sft >>= 1) yo[o] += __shfl_xor(yo[o], sft);
       }
-    const long long src = idx ? idx[row] : first + row;
-    float gy[FF_MAXO];
+    const int lrow = (int)(row - r0);
+    const long long src = s_src[lrow];
+    float gy[OT];
 #pragma unroll
-    for (int o = 0; o < FF_MAXO; ++o) {
+    for (int o = 0; o < OT; ++o) {
       gy[o] = 0.f;
       if (o < O) {
         const float yy = yo[o] + bfr[o];
-        const float dlt = yy - target[src * O + o];
+        const float dlt = yy - s_tg[lrow * FF_MAXO + o];
         gy[o] = gscale * dlt;
         if (lane == o) {
           y[row * O + o] = yy;
@@ -495,7 +536,7 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
       if (!live[ps]) continue;
       f32x4 gr = {0.f, 0.f, 0.f, 0.f}, gi = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int o = 0; o < FF_MAXO; ++o)
+      for (int o = 0; o < OT; ++o)
         if (o < O) {
           gr += gy[o] * wre[ps][o];
           gi += gy[o] * wim[ps][o];
@@ -513,6 +554,21 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
       *reinterpret_cast<f32x4*>(g_lin + o_) = glr;
       *reinterpret_cast<f32x4*>(g_lin + o_ + 32) = gli;
     }
+  };
+#pragma unroll
+  for (int d = 0; d < PF; ++d) load_row(d, r0 + wave + 4 * d);
+  for (long long row = r0 + wave; row < r1; row += 4 * PF) {
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+      const long long rr_ = row + 4 * d;
+      if (rr_ < r1) {                                   // wave-uniform
+        f32x4 zr[NPASS], zi[NPASS], lr[NPASS], li[NPASS];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) { zr[ps] = nzr[d][ps]; zi[ps] = nzi[d][ps]; lr[ps] = nlr[d][ps]; li[ps] = nli[d][ps]; }
+        load_row(d, rr_ + 4 * PF);
+        process(rr_, zr, zi, lr, li);
+      }
+    }
   }
 
   // ---- combine the 4 waves: g_wf partials [O][P], bias partial [O], loss
@@ -522,7 +578,7 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
   for (int ps = 0; ps < NPASS; ++ps)
     if (live[ps])
 #pragma unroll
-      for (int o = 0; o < FF_MAXO; ++o)
+      for (int o = 0; o < OT; ++o)
         if (o < O) {
           *reinterpret_cast<f32x4*>(swf + ((size_t)wave * O + o) * P + col[ps]) = are[ps][o];
           *reinterpret_cast<f32x4*>(swf + ((size_t)wave * O + o) * P + col[ps] + 32) = aim[ps][o];
@@ -530,7 +586,7 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
   // lsum is identical in every lane only per row-term count; every lane added the same terms -> use lane 0
   if (lane == 0) {
 #pragma unroll
-    for (int o = 0; o < FF_MAXO; ++o) sb[wave * (FF_MAXO + 1) + o] = bsum[o];
+    for (int o = 0; o < OT; ++o) sb[wave * (FF_MAXO + 1) + o] = bsum[o];
     sb[wave * (FF_MAXO + 1) + FF_MAXO] = lsum;
   }
   __syncthreads();
@@ -546,7 +602,8 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
                                (sb[2 * (FF_MAXO + 1) + FF_MAXO] + sb[3 * (FF_MAXO + 1) + FF_MAXO]);
 }
 
-hipError_t launch_final_fused(hipStream_t s, const float* out, const float* lin, int64_t n, int P, int O,
+// out = nullptr: out_L is recomputed from lin_L (kvalid = number of valid complex features)
+hipError_t launch_final_fused(hipStream_t s, const float* out, const float* lin, int64_t n, int P, int O, int kvalid,
                               const float* wf, const float* bfr, const float* target, const int64_t* idx,
                               int64_t first, float weight, float omega, float scale, float* y, float* rec,
                               float* g_lin, float* part_w, float* part_b, float* loss_partial,
@@ -555,15 +612,22 @@ hipError_t launch_final_fused(hipStream_t s, const float* out, const float* lin,
   if (!final_fused_supported(P, O)) return hipErrorInvalidValue;
   const int nblk = final_bwd_blocks(n);
   const float inv = (float)(1.0 / ((double)n * (double)O));
-  const size_t shm = ((size_t)4 * O * P + 4 * (FF_MAXO + 1)) * sizeof(float);
-  if (P <= 512)
-    hipLaunchKernelGGL(final_fused_kernel<1>, dim3((unsigned)nblk), dim3(256), shm, s, out, lin, (long long)n, P,
-                       O, wf, bfr, target, idx, (long long)first, weight * 2.f * inv, omega, scale, y, rec,
-                       g_lin, part_w, part_b, loss_partial);
-  else
-    hipLaunchKernelGGL(final_fused_kernel<2>, dim3((unsigned)nblk), dim3(256), shm, s, out, lin, (long long)n, P,
-                       O, wf, bfr, target, idx, (long long)first, weight * 2.f * inv, omega, scale, y, rec,
-                       g_lin, part_w, part_b, loss_partial);
+  const size_t shm = final_fused_shm(P, O);
+#define FF_LAUNCH(NP, RC, OT)                                                                                \
+  hipLaunchKernelGGL((final_fused_kernel<NP, RC, OT>), dim3((unsigned)nblk), dim3(256), shm, s, out, lin,  \
+                     (long long)n, P, O, kvalid, wf, bfr, target, idx, (long long)first, weight * 2.f * inv, \
+                     omega, scale, y, rec, g_lin, part_w, part_b, loss_partial)
+#define FF_LAUNCH_O(NP, RC)                                                                                  \
+  switch (O) {                                                                                               \
+    case 1: FF_LAUNCH(NP, RC, 1); break;                                                                     \
+    case 2: FF_LAUNCH(NP, RC, 2); break;                                                                     \
+    case 3: FF_LAUNCH(NP, RC, 3); break;                                                                     \
+    default: FF_LAUNCH(NP, RC, 4); break;                                                                    \
+  }
+  if (P <= 512) { if (out) { FF_LAUNCH_O(1, false); } else { FF_LAUNCH_O(1, true); } }
+  else { if (out) { FF_LAUNCH_O(2, false); } else { FF_LAUNCH_O(2, true); } }
+#undef FF_LAUNCH_O
+#undef FF_LAUNCH
   // the loss partials are summed by the MSE final kernel (one block)
   hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, s, loss_partial, nblk, weight * inv, loss_out);
   return hipGetLastError();
