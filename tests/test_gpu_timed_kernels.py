@@ -282,3 +282,33 @@ def test_fused_trainer_step_gradients_vs_fp64_oracle(case):
                                   resid_max=np.abs(y64 - tgt).max())
         else:
             within_ref(relmax(mine, ref), relmax(ref32, ref), f"{tag} grad {name}")
+
+
+def test_recompute_out_is_bit_identical():
+    """Knob "recompute_out" (default 1; wire_api.hip): on the 16x16x32 kernels the data-gradient epilogues and the
+    fused final stage evaluate out = exp(j w0 lin - s0^2 |lin|^2) again from the stored lin (modules/wire.py:90-93)
+    instead of reading the stored out, and the last hidden layer stores no out at all.  Same lean form as the forward
+    epilogue -> the step must not change by a single bit: loss, reconstruction and every gradient."""
+    from wire_amd import _lib
+    from wire_amd.trainer import FusedTrainer
+    L = _lib.lib()
+    assert L.wire_tune_get(b"recompute_out") == 1
+    res = []
+    for knob in (0, 1):
+        _lib.check(L.wire_tune_set(b"recompute_out", knob))
+        try:
+            model = _wire_model(4, 20.0, 30.0, hf=363, D=2, O=3, seed=3)
+            g = torch.Generator().manual_seed(5)
+            N = 128 * 128
+            target = torch.rand(N, 3, generator=g)
+            perm = torch.randperm(N, generator=g).to(DEV)
+            tr = FusedTrainer(model, (128, 128), target, lr=0.0, keep_rec=True)
+            loss = tr.step(perm)
+            torch.cuda.synchronize()
+            res.append((loss.clone(), tr.rec.clone(), tr.flat_grad.clone()))
+        finally:
+            _lib.check(L.wire_tune_set(b"recompute_out", 1))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][2], res[1][2])
+    assert float(res[0][2].abs().max()) > 0

@@ -337,20 +337,44 @@ extern "C" int wire_pack_params(void* stream, const wire_net_desc* d, const void
   ProfScope ps(s, 3, 0);
   for (int i = 0; i < p.ntens; ++i)
     if (!params[i]) return fail(WIRE_ERR_ARG, "params[%d] is null", i);
-  for (int l = p.first_gemm ? 0 : 1; l <= p.L; ++l) {
-    const float* W = (const float*)params[p.per_layer * l];
-    const float* b = (const float*)params[p.per_layer * l + 1];
-    const float* V = p.per_layer == 4 ? (const float*)params[p.per_layer * l + 2] : nullptr;
-    const float* c = p.per_layer == 4 ? (const float*)params[p.per_layer * l + 3] : nullptr;
-    const int kin = (l == 0) ? p.Din : p.K;
-    const int pin = (l == 0) ? p.Pin0 : p.P;
-    HIPCHK(launch_pack_hidden(s, p.kind, W, b, V, c, p.K, kin, p.P, pin, packed + p.off_fwd[l],
-                              packed + p.off_dg[l], packed + p.off_bias[l]));
-    HIPCHK(launch_x3_split_b(s, packed + p.off_fwd[l], pin, p.Pl, pin, packed + p.off_fwd_x3[l]));
-    HIPCHK(launch_x3_split_b(s, packed + p.off_dg[l], p.Pl, pin, p.Pl, packed + p.off_dg_x3[l]));
-    if (p.off_fwd_3m[l] >= 0)     // same bias image (blocked planar) as launch_pack_hidden wrote
-      HIPCHK(launch_pack3m(s, W, b, p.K, p.K, p.Kp, p.Kp, packed + p.off_fwd_3m[l], packed + p.off_dg_3m[l],
-                           packed + p.off_bias[l]));
+  if (p.first_gemm) {                                    // layer 0 as a GEMM (positional encoding): its own shape
+    const float* W = (const float*)params[0];
+    const float* b = (const float*)params[1];
+    HIPCHK(launch_pack_hidden(s, p.kind, W, b, nullptr, nullptr, p.K, p.Din, p.P, p.Pin0, packed + p.off_fwd[0],
+                              packed + p.off_dg[0], packed + p.off_bias[0]));
+    HIPCHK(launch_x3_split_b(s, packed + p.off_fwd[0], p.Pin0, p.Pl, p.Pin0, packed + p.off_fwd_x3[0]));
+    HIPCHK(launch_x3_split_b(s, packed + p.off_dg[0], p.Pl, p.Pin0, p.Pl, packed + p.off_dg_x3[0]));
+  }
+  // hidden layers share one shape: every family's image of up to PACK_MAXB layers per launch (3 - 4 launches per step
+  // instead of 4 per layer; this runs once per optimizer step and is all launch gaps)
+  for (int l0 = 1; l0 <= p.L; l0 += PACK_MAXB) {
+    const int nb = (p.L - l0 + 1) < PACK_MAXB ? (p.L - l0 + 1) : PACK_MAXB;
+    PackBatch pb{}, p3{};
+    X3SplitBatch sf{}, sd{};
+    for (int i = 0; i < nb; ++i) {
+      const int l = l0 + i;
+      pb.W[i] = (const float*)params[p.per_layer * l];
+      pb.b[i] = (const float*)params[p.per_layer * l + 1];
+      pb.V[i] = p.per_layer == 4 ? (const float*)params[p.per_layer * l + 2] : nullptr;
+      pb.c[i] = p.per_layer == 4 ? (const float*)params[p.per_layer * l + 3] : nullptr;
+      pb.fwd[i] = packed + p.off_fwd[l]; pb.dg[i] = packed + p.off_dg[l]; pb.bias[i] = packed + p.off_bias[l];
+      sf.src[i] = packed + p.off_fwd[l]; sf.dst[i] = packed + p.off_fwd_x3[l];
+      sd.src[i] = packed + p.off_dg[l]; sd.dst[i] = packed + p.off_dg_x3[l];
+      if (p.off_fwd_3m[l] >= 0) {
+        p3.W[i] = pb.W[i]; p3.b[i] = pb.b[i];
+        p3.fwd[i] = packed + p.off_fwd_3m[l]; p3.dg[i] = packed + p.off_dg_3m[l]; p3.bias[i] = packed + p.off_bias[l];
+      }
+    }
+    HIPCHK(launch_pack_hidden_batch(s, p.kind, pb, nb, p.K, p.K, p.P, p.P));
+    if (p.Pl == p.P) {                                   // forward and transposed images have one shape: one launch
+      for (int i = 0; i < nb; ++i) { sf.src[nb + i] = sd.src[i]; sf.dst[nb + i] = sd.dst[i]; }
+      HIPCHK(launch_x3_split_b_batch(s, sf, 2 * nb, p.P, p.Pl, p.P));
+    } else {
+      HIPCHK(launch_x3_split_b_batch(s, sf, nb, p.P, p.Pl, p.P));
+      HIPCHK(launch_x3_split_b_batch(s, sd, nb, p.Pl, p.P, p.Pl));
+    }
+    if (p.off_fwd_3m[l0] >= 0)    // same bias image (blocked planar) as the hidden pack wrote
+      HIPCHK(launch_pack3m_batch(s, p3, nb, p.K, p.K, p.Kp, p.Kp));
   }
   HIPCHK(launch_pack_final(s, p.kind, (const float*)params[p.ntens - 2],
                            (const float*)params[p.ntens - 1], p.K, p.P, p.O, packed + p.off_wf,

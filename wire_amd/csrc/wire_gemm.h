@@ -72,6 +72,9 @@ hipError_t launch_gemm3m_tn(hipStream_t s, const float* G, int ldg, const float*
 // launch_x3_split_b writes from the fp32 image Bt[Nc][ldb] (gemmx3_b_image_floats(Nc, Kd) floats).
 int64_t gemmx3_b_image_floats(int Nc, int Kd);
 hipError_t launch_x3_split_b(hipStream_t s, const float* Bt, int ldb, int Nc, int Kd, void* Bx3);
+#define X3_SPLIT_MAXB 32
+struct X3SplitBatch { const float* src[X3_SPLIT_MAXB]; void* dst[X3_SPLIT_MAXB]; };
+hipError_t launch_x3_split_b_batch(hipStream_t s, const X3SplitBatch& sb, int nb, int ldb, int Nc, int Kd);
 hipError_t launch_gemmx3_nt(hipStream_t s, int epi, const float* A, int lda, const void* Bx3, int64_t M,
                             int Nc, int Kd, const GemmEpiParams& ep);
 int gemmx3_tune_set(const char* key, int value);

@@ -101,8 +101,8 @@ typedef float x3f32x4 __attribute__((ext_vector_type(4)));
 //   bit 3 of c is set: the LDS bank swizzle)
 // so that the 4 KB of one (tile, stage, plane) are contiguous: thread t of the GEMM loads bytes [16 t, 16 t + 16).
 // ---------------------------------------------------------------------------
-__global__ void x3_split_b_kernel(const float* __restrict__ Bt, int ldb, int Nc, int Kd, int nk,
-                                  unsigned short* __restrict__ Bx3) {
+WIRE_DEVINL void x3_split_b_body(const float* __restrict__ Bt, int ldb, int Nc, int Kd, int nk,
+                                 unsigned short* __restrict__ Bx3) {
   const int k2 = (blockIdx.x * blockDim.x + threadIdx.x) * 2;   // pair of reduction indices
   const int j = blockIdx.y;                                     // column, < tiles_n * 128
   if (k2 >= Kd) return;
@@ -128,6 +128,15 @@ __global__ void x3_split_b_kernel(const float* __restrict__ Bt, int ldb, int Nc,
   *reinterpret_cast<unsigned*>(Bu + ubase + 2 * 128 * 16) = L;
 }
 
+__global__ void x3_split_b_kernel(const float* __restrict__ Bt, int ldb, int Nc, int Kd, int nk,
+                                  unsigned short* __restrict__ Bx3) {
+  x3_split_b_body(Bt, ldb, Nc, Kd, nk, Bx3);
+}
+// several images of one shape per launch (blockIdx.z): the per-step repacking of all layers in one go
+__global__ void x3_split_b_batch_kernel(X3SplitBatch sb, int ldb, int Nc, int Kd, int nk) {
+  x3_split_b_body(sb.src[blockIdx.z], ldb, Nc, Kd, nk, (unsigned short*)sb.dst[blockIdx.z]);
+}
+
 int64_t gemmx3_b_image_floats(int Nc, int Kd) {
   const int64_t tiles_n = (Nc + X3_BN - 1) / X3_BN;
   // 3 bf16 planes = 1.5 floats per element; two images (bank-swizzled for the 32 x 32 x 16 kernels, plain for the
@@ -141,6 +150,14 @@ hipError_t launch_x3_split_b(hipStream_t s, const float* Bt, int ldb, int Nc, in
   dim3 grid((unsigned)((Kd / 2 + 127) / 128), (unsigned)(tiles_n * 128));
   hipLaunchKernelGGL(x3_split_b_kernel, grid, dim3(128), 0, s, Bt, ldb, Nc, Kd, Kd / X3_BK,
                      (unsigned short*)Bx3);
+  return hipGetLastError();
+}
+
+hipError_t launch_x3_split_b_batch(hipStream_t s, const X3SplitBatch& sb, int nb, int ldb, int Nc, int Kd) {
+  if ((Kd & 15) || (ldb & 1) || nb < 1 || nb > X3_SPLIT_MAXB) return hipErrorInvalidValue;
+  const int tiles_n = (Nc + X3_BN - 1) / X3_BN;
+  dim3 grid((unsigned)((Kd / 2 + 127) / 128), (unsigned)(tiles_n * 128), (unsigned)nb);
+  hipLaunchKernelGGL(x3_split_b_batch_kernel, grid, dim3(128), 0, s, sb, ldb, Nc, Kd, Kd / X3_BK);
   return hipGetLastError();
 }
 

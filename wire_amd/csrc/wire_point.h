@@ -9,6 +9,15 @@ enum { NK_WIRE = 0, NK_WIRE2D = 1, NK_SIREN = 2, NK_GAUSS = 3, NK_RELU = 4 };
 hipError_t launch_pack_hidden(hipStream_t s, int kind, const float* W, const float* b,
                               const float* V, const float* c, int K, int Kin, int P, int Pin,
                               float* Bt_fwd, float* Bt_dgrad, float* bias);
+// several layers of one shape per launch (grid.z = layer)
+#define PACK_MAXB 16
+struct PackBatch {
+  const float* W[PACK_MAXB]; const float* b[PACK_MAXB]; const float* V[PACK_MAXB]; const float* c[PACK_MAXB];
+  float* fwd[PACK_MAXB]; float* dg[PACK_MAXB]; float* bias[PACK_MAXB];
+};
+hipError_t launch_pack_hidden_batch(hipStream_t s, int kind, const PackBatch& pb, int nb, int K, int Kin, int P,
+                                    int Pin);
+hipError_t launch_pack3m_batch(hipStream_t s, const PackBatch& pb, int nb, int K, int Kin, int Kp, int Kpin);
 hipError_t launch_pack_final(hipStream_t s, int kind, const float* Wf, const float* bf, int K,
                              int P, int O, float* wf, float* bfr);
 

@@ -21,10 +21,10 @@ static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1
 //     [ (o,re),(i,re) ] =  W_re   [ (o,re),(i,im) ] = -W_im
 //     [ (o,im),(i,re) ] =  W_im   [ (o,im),(i,im) ] =  W_re
 // The data-gradient GEMM g_z = g_lin conj(W) uses exactly the transposed image.
-__global__ void pack_hidden_kernel(int kind, const float* __restrict__ W, const float* __restrict__ b,
-                                   const float* __restrict__ V, const float* __restrict__ c, int K,
-                                   int Kin, int P, int Pin, int Nc, float* __restrict__ Bt_fwd,
-                                   float* __restrict__ Bt_dgrad, float* __restrict__ bias) {
+WIRE_DEVINL void pack_hidden_body(int kind, const float* __restrict__ W, const float* __restrict__ b,
+                                  const float* __restrict__ V, const float* __restrict__ c, int K,
+                                  int Kin, int P, int Pin, int Nc, float* __restrict__ Bt_fwd,
+                                  float* __restrict__ Bt_dgrad, float* __restrict__ bias) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;   // input (reduction) index
   const int j = blockIdx.y;                              // GEMM output column
   if (k >= Pin) return;
@@ -60,6 +60,26 @@ __global__ void pack_hidden_kernel(int kind, const float* __restrict__ W, const 
   Bt_fwd[(size_t)j * Pin + k] = val;
   Bt_dgrad[(size_t)k * Nc + j] = val;
   if (k == 0) bias[j] = bv;
+}
+__global__ void pack_hidden_kernel(int kind, const float* __restrict__ W, const float* __restrict__ b,
+                                   const float* __restrict__ V, const float* __restrict__ c, int K,
+                                   int Kin, int P, int Pin, int Nc, float* __restrict__ Bt_fwd,
+                                   float* __restrict__ Bt_dgrad, float* __restrict__ bias) {
+  pack_hidden_body(kind, W, b, V, c, K, Kin, P, Pin, Nc, Bt_fwd, Bt_dgrad, bias);
+}
+// the same for up to PACK_MAXB layers of one shape in one launch (blockIdx.z = layer): wire_pack_params runs once per
+// optimizer step, and a chain of ~5 us launches per layer costs more in launch gaps than in work
+__global__ void pack_hidden_batch_kernel(int kind, PackBatch pb, int K, int Kin, int P, int Pin, int Nc) {
+  const int z = blockIdx.z;
+  pack_hidden_body(kind, pb.W[z], pb.b[z], pb.V[z], pb.c[z], K, Kin, P, Pin, Nc, pb.fwd[z], pb.dg[z], pb.bias[z]);
+}
+hipError_t launch_pack_hidden_batch(hipStream_t s, int kind, const PackBatch& pb, int nb, int K, int Kin, int P,
+                                    int Pin) {
+  if (nb < 1 || nb > PACK_MAXB) return hipErrorInvalidValue;
+  const int Nc = (kind == NK_WIRE2D) ? 2 * P : P;
+  dim3 grid(cdiv(Pin, 128), (unsigned)Nc, (unsigned)nb);
+  hipLaunchKernelGGL(pack_hidden_batch_kernel, grid, dim3(128), 0, s, kind, pb, K, Kin, P, Pin, Nc);
+  return hipGetLastError();
 }
 
 hipError_t launch_pack_hidden(hipStream_t s, int kind, const float* W, const float* b,
@@ -1413,9 +1433,9 @@ hipError_t launch_metric(hipStream_t s, int mode, const float* rec, const float*
 //   Wb_fwd[o][(i,re|im)] = W[o][i]            (lin = z W^T)
 //   Wb_dg [i][(o,re|im)] = conj(W[o][i])      (g_z = g_lin conj(W))
 // ===========================================================================
-__global__ void pack3m_kernel(const float* __restrict__ W, const float* __restrict__ b, int K, int Kin,
-                              int Kp, int Kpin, float* __restrict__ Wb_fwd, float* __restrict__ Wb_dg,
-                              float* __restrict__ bias) {
+WIRE_DEVINL void pack3m_body(const float* __restrict__ W, const float* __restrict__ b, int K, int Kin,
+                             int Kp, int Kpin, float* __restrict__ Wb_fwd, float* __restrict__ Wb_dg,
+                             float* __restrict__ bias) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;   // input feature (padded)
   const int o = blockIdx.y;                              // output feature (padded)
   if (i >= Kpin) return;
@@ -1433,6 +1453,22 @@ __global__ void pack3m_kernel(const float* __restrict__ W, const float* __restri
     bias[co] = o < K ? b[2 * o] : 0.f;
     bias[co + 32] = o < K ? b[2 * o + 1] : 0.f;
   }
+}
+__global__ void pack3m_kernel(const float* __restrict__ W, const float* __restrict__ b, int K, int Kin,
+                              int Kp, int Kpin, float* __restrict__ Wb_fwd, float* __restrict__ Wb_dg,
+                              float* __restrict__ bias) {
+  pack3m_body(W, b, K, Kin, Kp, Kpin, Wb_fwd, Wb_dg, bias);
+}
+__global__ void pack3m_batch_kernel(PackBatch pb, int K, int Kin, int Kp, int Kpin) {
+  const int z = blockIdx.z;
+  pack3m_body(pb.W[z], pb.b[z], K, Kin, Kp, Kpin, pb.fwd[z], pb.dg[z], pb.bias[z]);
+}
+// up to PACK_MAXB layers per launch: pb.fwd / pb.dg / pb.bias = the 3M images and the (shared) blocked bias
+hipError_t launch_pack3m_batch(hipStream_t s, const PackBatch& pb, int nb, int K, int Kin, int Kp, int Kpin) {
+  if (nb < 1 || nb > PACK_MAXB) return hipErrorInvalidValue;
+  dim3 grid(cdiv(Kpin, 64), (unsigned)Kp, (unsigned)nb);
+  hipLaunchKernelGGL(pack3m_batch_kernel, grid, dim3(64), 0, s, pb, K, Kin, Kp, Kpin);
+  return hipGetLastError();
 }
 hipError_t launch_pack3m(hipStream_t s, const float* W, const float* b, int K, int Kin, int Kp, int Kpin,
                          float* Wb_fwd, float* Wb_dg, float* bias) {
