@@ -312,3 +312,62 @@ def test_recompute_out_is_bit_identical():
     assert torch.equal(res[0][1], res[1][1])
     assert torch.equal(res[0][2], res[1][2])
     assert float(res[0][2].abs().max()) > 0
+
+
+KIND_CASES = {
+    # name: (get_INR kwargs, grid)  -- rows = a few 256-row blocks of the fused final stage plus a ragged one
+    "wire": (dict(nonlin="wire", hidden_features=91, first_omega_0=7.0, hidden_omega_0=7.0, scale=6.0), (37, 29)),
+    "wire_O1": (dict(nonlin="wire", hidden_features=91, out_features=1, first_omega_0=7.0, hidden_omega_0=7.0,
+                     scale=6.0), (37, 29)),
+    "wire2d": (dict(nonlin="wire2d", hidden_features=64, first_omega_0=5.0, hidden_omega_0=5.0, scale=4.0), (37, 29)),
+    "siren": (dict(nonlin="siren", hidden_features=96, first_omega_0=30.0, hidden_omega_0=30.0), (37, 29)),
+    "gauss": (dict(nonlin="gauss", hidden_features=96, scale=10.0), (37, 29)),
+    "relu": (dict(nonlin="relu", hidden_features=96), (37, 29)),
+    "relu_posenc": (dict(nonlin="relu", hidden_features=96, pos_encode=True, sidelength=37), (37, 29)),
+    "siren_big": (dict(nonlin="siren", hidden_features=256, first_omega_0=30.0, hidden_omega_0=30.0), (96, 64)),
+    "wire2d_big": (dict(nonlin="wire2d", hidden_features=181, first_omega_0=5.0, hidden_omega_0=5.0, scale=4.0),
+                   (96, 64)),
+}
+
+
+@pytest.mark.parametrize("case", list(KIND_CASES))
+def test_fused_step_equals_autograd_path_every_kind(case):
+    """FusedTrainer.step (wire_train_fwd_bwd: forward, the FUSED final stage -- final linear + MSE + final backward +
+    activation gradient of the last hidden layer in one pass, wire_point.hip final_fused_kernel, every net kind --
+    and the backward) against the autograd path of the same module on the same batch: ``model(coords)`` ->
+    ``((pix - gt)**2).mean()`` -> ``backward()`` (wire_image_denoise.py:146-156), which runs the unfused kernels
+    (wire_mlp_fwd / wire_mlp_bwd).  Output, loss and every parameter gradient, scale-relative 2e-5."""
+    from wire_amd.modules import models
+    from wire_amd.trainer import FusedTrainer
+    kw, grid = KIND_CASES[case]
+    kw = dict(kw)
+    O = kw.pop("out_features", 3)
+    torch.manual_seed(1)
+    model = models.get_INR(in_features=2, out_features=O, hidden_layers=2, **kw).to(DEV)
+    N = grid[0] * grid[1]
+    g = torch.Generator().manual_seed(2)
+    target = torch.rand(N, O, generator=g)
+    perm = torch.randperm(N, generator=g)
+    tr = FusedTrainer(model, grid, target, lr=0.0, keep_rec=True)
+    loss = tr.step(perm.to(DEV))
+    torch.cuda.synchronize()
+    flat = tr.flat_grad.clone()
+    rec = tr.rec.clone()
+    # autograd path on the same rows
+    coords = torch.tensor(wo.image_coords(*grid))[perm].to(DEV)
+    model.zero_grad()
+    pix = model(coords[None])[0]
+    ref_loss = ((pix - target.to(DEV)[perm]) ** 2).mean()
+    ref_loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
+    e_y = relmax(rec.cpu().numpy()[perm.numpy()], pix.detach().cpu().numpy())
+    assert e_y <= 1e-5, f"{case} y {e_y:.2e}"
+    names = [k for k in model.state_dict().keys() if "omega_0" not in k and "scale_0" not in k]
+    params = dict(model.named_parameters())
+    for name, off in zip(names, tr.offsets):
+        ref = params[name].grad.detach()
+        ref = torch.view_as_real(ref).reshape(-1) if ref.is_complex() else ref.reshape(-1)
+        mine = flat[off:off + ref.numel()]
+        e = relmax(mine.cpu().numpy(), ref.cpu().numpy())
+        assert e <= 2e-5, f"{case} grad {name}: {e:.2e}"

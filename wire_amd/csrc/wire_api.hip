@@ -624,7 +624,9 @@ extern "C" int wire_train_fwd_bwd(void* stream, const wire_net_desc* d, const fl
   if (n <= 0) return fail(WIRE_ERR_ARG, "wire_train_fwd_bwd needs n > 0");
   if (!target || !y || !g_y || !loss_out || !partial) return fail(WIRE_ERR_ARG, "null pointer");
   hipStream_t s = (hipStream_t)stream;
-  const bool fuse = (p.kind == WIRE_KIND_WIRE) && p.L >= 1 && p.O <= 4 && final_fused_supported(p.P, p.O);
+  // every net kind with at least one hidden layer: final linear + loss + final backward + activation gradient of layer L
+  // in one pass (wire_point.hip: final_fused_kernel)
+  const bool fuse = p.L >= 1 && p.O <= 4 && final_fused_supported(p.P, p.O);
   if (!fuse) {
     if (int rc = mlp_fwd_core(stream, p, packed, coords, n, y, act, act_bytes, 1, true)) return rc;
     { ProfScope ps(s, 3, 0);
@@ -633,7 +635,7 @@ extern "C" int wire_train_fwd_bwd(void* stream, const wire_net_desc* d, const fl
   }
   // with layer L on the 16 x 16 x 32 forward kernel (lean epilogue) the final stage evaluates out_L from lin_L itself,
   // bit for bit what that epilogue would have stored: out_L is neither written nor read (1 GB less HBM traffic)
-  const bool recomp = g_recompute_out && p.x3 && gemmx3_nt_is_h16(EPI_GABOR_FWD, n);
+  const bool recomp = g_recompute_out && p.x3 && p.kind == WIRE_KIND_WIRE && gemmx3_nt_is_h16(EPI_GABOR_FWD, n);
   if (int rc = mlp_fwd_core(stream, p, packed, coords, n, nullptr, act, act_bytes, 1, false, recomp)) return rc;
   const ActLayout a = act_layout(p, n, 1);
   const ScratchLayout sc = scratch_layout(p, n);
@@ -644,8 +646,9 @@ extern "C" int wire_train_fwd_bwd(void* stream, const wire_net_desc* d, const fl
     // final linear forward + MSE (loss, rec) + final linear backward + Gabor gradient of layer L:
     // one pass over out_L / lin_L instead of three
     ProfScope ps(s, 3, 0);
-    HIPCHK(launch_final_fused(s, recomp ? nullptr : A + a.out0 + (int64_t)p.L * n * p.P,
-                              A + a.lin1 + (int64_t)(p.L - 1) * n * p.Pl, n, p.P, p.O, p.K, packed + p.off_wf, packed + p.off_bf, target, idx, first, weight,
+    const float* linL = p.kind == WIRE_KIND_RELU ? nullptr : A + a.lin1 + (int64_t)(p.L - 1) * n * p.Pl;
+    HIPCHK(launch_final_fused(s, p.kind, recomp ? nullptr : A + a.out0 + (int64_t)p.L * n * p.P, linL, n, p.P, p.O,
+                              p.K, packed + p.off_wf, packed + p.off_bf, target, idx, first, weight,
                               p.w, p.s, y, rec, Sx + sc.ga, Sx + sc.fpw, Sx + sc.fpb, Sx + sc.crp, loss_out));
   }
   return mlp_bwd_core(stream, p, packed, coords, n, nullptr, act, act_bytes, scratch, scratch_bytes, grads, false);

@@ -48,8 +48,8 @@ hipError_t launch_final_reduce(hipStream_t s, int kind, float* part_w, float* pa
 // rec scatter, g_out = g_y conj(Wf), Gabor gradient of layer L, and the per-block partials of g_Wf /
 // g_bf in the SAME layout launch_final_bwd produces (FB_ROWS rows per block) for launch_final_reduce.
 bool final_fused_supported(int P, int O);
-hipError_t launch_final_fused(hipStream_t s, const float* out, const float* lin, int64_t n, int P, int O, int kvalid,
-                              const float* wf, const float* bfr, const float* target, const int64_t* idx,
+hipError_t launch_final_fused(hipStream_t s, int kind, const float* out, const float* lin, int64_t n, int P, int O,
+                              int kvalid, const float* wf, const float* bfr, const float* target, const int64_t* idx,
                               int64_t first, float weight, float omega, float scale, float* y, float* rec,
                               float* g_lin, float* part_w, float* part_b, float* loss_partial,
                               float* loss_out);

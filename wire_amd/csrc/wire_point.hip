@@ -419,35 +419,47 @@ bool final_fused_supported(int P, int O) {
   return (P % 64) == 0 && P <= 512 * FF_MAXPASS && O <= FF_MAXO && final_fused_shm(P, O) <= 65536;
 }
 
-// RECOMP: out_L is not read -- it is evaluated again from lin_L with the lean forward form (bit-identical to what the
-// 16 x 16 x 32 forward epilogue would have stored; wire_api.hip selects this only when that kernel ran layer L, and
-// then does not let it write out_L at all): 1 GB instead of 1.5 GB of HBM traffic for this pass.
-// OT = O (1..FF_MAXO): the weight / partial-sum registers are sized for the actual number of outputs
-template <int NPASS, bool RECOMP, int OT>
+// KIND: the activation whose gradient is fused (wire / wire2d: complex pairs (re | im) 32 columns apart; siren / gauss /
+//   relu: the two 4-column chunks of a lane are just 8 real features).  wire2d: lin is the 2P-wide (lin | sy) row.
+// RECOMP (wire only): out_L is not read -- it is evaluated again from lin_L with the lean forward form (bit-identical
+//   to what the 16 x 16 x 32 forward epilogue would have stored; wire_api.hip selects this only when that kernel ran
+//   layer L, and then does not let it write out_L at all): 1 GB instead of 1.5 GB of HBM traffic for this pass.
+// OT >= O (1..FF_MAXO): the weight / partial-sum registers are sized for the actual number of outputs
+// RPW: rows per wave slot -- 2 when a row has at most 256 floats (siren / gauss / relu and wire2d at 256 features):
+// lanes 0-31 take one row, lanes 32-63 the next, instead of leaving half the wave idle
+template <int NPASS, int KIND, bool RECOMP, int OT, int RPW>
 __global__ __launch_bounds__(256) void final_fused_kernel(
     const float* __restrict__ out, const float* __restrict__ lin, long long n, int P, int O, int kvalid,
     const float* __restrict__ wf, const float* __restrict__ bfr, const float* __restrict__ target,
     const int64_t* __restrict__ idx, long long first, float gscale, float omega, float scale,
     float* __restrict__ y, float* __restrict__ rec, float* __restrict__ g_lin, float* __restrict__ part_w,
     float* __restrict__ part_b, float* __restrict__ loss_partial) {
+  static_assert(!RECOMP || KIND == NK_WIRE, "recompute exists for the wire activation only");
+  static_assert(RPW == 1 || (RPW == 2 && NPASS == 1), "two rows per wave slot: one pass of at most 256 columns");
+  constexpr int RL = 64 / RPW;                         // lanes of one row
+  constexpr bool HAS_LIN = (KIND != NK_RELU);          // relu: lin is never stored (lin > 0 <=> out > 0)
+  constexpr int NL = (KIND == NK_WIRE2D) ? 4 : 2;      // 4-column chunks of lin per lane and pass
   extern __shared__ float sm[];                        // [4 waves][O][P] g_wf partials + [4][O+1]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / RL, lr_ = lane & (RL - 1);    // row of the slot, lane inside the row
   const int ngrp = P >> 6;
+  const int Pl = (KIND == NK_WIRE2D) ? 2 * P : P;      // row stride of lin / g_lin
   const long long r0 = (long long)blockIdx.x * FB_ROWS;
   long long r1 = r0 + FB_ROWS;
   if (r1 > n) r1 = n;
   const float m2s2 = -2.f * scale * scale;
 
   // this lane's columns and weights
-  int col[NPASS];
+  int col[NPASS], lcol[NPASS];
   bool live[NPASS];
   f32x4 wre[NPASS][OT], wim[NPASS][OT];
   f32x4 are[NPASS][OT], aim[NPASS][OT];
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
-    const int g = (lane >> 3) + 8 * ps;
+    const int g = (lr_ >> 3) + 8 * ps;
     live[ps] = g < ngrp;
-    col[ps] = (g << 6) + 4 * (lane & 7);
+    col[ps] = (g << 6) + 4 * (lr_ & 7);
+    lcol[ps] = (KIND == NK_WIRE2D) ? (g << 7) + 4 * (lr_ & 7) : col[ps];
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -473,7 +485,8 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
       const long long src = idx ? idx[grow] : first + grow;
       s_src[threadIdx.x] = src;
 #pragma unroll
-      for (int o = 0; o < OT; ++o) s_tg[threadIdx.x * FF_MAXO + o] = target[src * O + o];
+      for (int o = 0; o < OT; ++o)
+        if (o < O) s_tg[threadIdx.x * FF_MAXO + o] = target[src * O + o];
     }
   }
   __syncthreads();
@@ -482,25 +495,33 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
   // flight while row r goes through its butterfly / gradient chain -- the pass is bound by memory latency, and one
   // row is only 4 KB (2 KB when out is recomputed) per wave in flight
   constexpr int PF = RECOMP ? 3 : 2;
-  f32x4 nzr[PF][NPASS], nzi[PF][NPASS], nlr[PF][NPASS], nli[PF][NPASS];
+  f32x4 nzr[PF][NPASS], nzi[PF][NPASS], nl[PF][NPASS][NL];
   auto load_row = [&](const int slot, long long row) {
+    row += sub;                                          // this lane's row of the slot
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-      nzr[slot][ps] = z4; nzi[slot][ps] = z4; nlr[slot][ps] = z4; nli[slot][ps] = z4;
+      nzr[slot][ps] = z4; nzi[slot][ps] = z4;
+#pragma unroll
+      for (int c = 0; c < NL; ++c) nl[slot][ps][c] = z4;
       if (live[ps] && row < r1) {
-        const size_t o_ = (size_t)row * P + col[ps];
         if (!RECOMP) {
+          const size_t o_ = (size_t)row * P + col[ps];
           nzr[slot][ps] = *reinterpret_cast<const f32x4*>(out + o_);
           nzi[slot][ps] = *reinterpret_cast<const f32x4*>(out + o_ + 32);
         }
-        nlr[slot][ps] = *reinterpret_cast<const f32x4*>(lin + o_);
-        nli[slot][ps] = *reinterpret_cast<const f32x4*>(lin + o_ + 32);
+        if (HAS_LIN) {
+          const float* Lp = lin + (size_t)row * Pl + lcol[ps];
+#pragma unroll
+          for (int c = 0; c < NL; ++c) nl[slot][ps][c] = *reinterpret_cast<const f32x4*>(Lp + 32 * c);
+        }
       }
     }
   };
-  auto process = [&](const long long row, f32x4 (&zr)[NPASS], f32x4 (&zi)[NPASS], const f32x4 (&lr)[NPASS],
-                     const f32x4 (&li)[NPASS]) {
+  auto process = [&](const long long row_slot, f32x4 (&zr)[NPASS], f32x4 (&zi)[NPASS],
+                     const f32x4 (&ll)[NPASS][NL]) {
+    const long long row = row_slot + sub;                // this lane's row; past the end: contributes nothing
+    const bool rl = row < r1;
     if (RECOMP) {
       const float w0l2e = omega * 1.44269502f, ns2l2e = -(scale * scale) * 1.44269502f;
 #pragma unroll
@@ -509,7 +530,7 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float a_, b_;
-          gabor_fwd_lean(lr[ps][j], li[ps][j], omega, w0l2e, ns2l2e, a_, b_);
+          gabor_fwd_lean(ll[ps][0][j], ll[ps][1][j], omega, w0l2e, ns2l2e, a_, b_);
           const bool valid = live[ps] && f0 + j < kvalid;          // pad features are 0
           zr[ps][j] = valid ? a_ : 0.f;
           zi[ps][j] = valid ? b_ : 0.f;
@@ -531,9 +552,9 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
     for (int o = 0; o < OT; ++o)
       if (o < O) {
 #pragma unroll
-        for (int sft = 32; sft >= 1; sft >>= 1) yo[o] += __shfl_xor(yo[o], sft);
+        for (int sft = RL / 2; sft >= 1; sft >>= 1) yo[o] += __shfl_xor(yo[o], sft);
       }
-    const int lrow = (int)(row - r0);
+    const int lrow = rl ? (int)(row - r0) : 0;
     const long long src = s_src[lrow];
     float gy[OT];
 #pragma unroll
@@ -541,9 +562,9 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
       gy[o] = 0.f;
       if (o < O) {
         const float yy = yo[o] + bfr[o];
-        const float dlt = yy - s_tg[lrow * FF_MAXO + o];
+        const float dlt = rl ? yy - s_tg[lrow * FF_MAXO + o] : 0.f;
         gy[o] = gscale * dlt;
-        if (lane == o) {
+        if (lr_ == o && rl) {
           y[row * O + o] = yy;
           if (rec) rec[src * O + o] = yy;
         }
@@ -553,7 +574,7 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
     }
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-      if (!live[ps]) continue;
+      if (!live[ps] || !rl) continue;
       f32x4 gr = {0.f, 0.f, 0.f, 0.f}, gi = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int o = 0; o < OT; ++o)
@@ -563,30 +584,64 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
           are[ps][o] += gy[o] * zr[ps];
           aim[ps][o] += gy[o] * zi[ps];
         }
-      f32x4 glr, gli;
+      float* Gp = g_lin + (size_t)row * Pl + lcol[ps];
+      if (KIND == NK_WIRE) {
+        f32x4 glr, gli;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float a_, b_;
-        gabor_bwd(gr[j], gi[j], lr[ps][j], li[ps][j], zr[ps][j], zi[ps][j], omega, m2s2, a_, b_);
-        glr[j] = a_; gli[j] = b_;
+        for (int j = 0; j < 4; ++j) {
+          float a_, b_;
+          gabor_bwd(gr[j], gi[j], ll[ps][0][j], ll[ps][1][j], zr[ps][j], zi[ps][j], omega, m2s2, a_, b_);
+          glr[j] = a_; gli[j] = b_;
+        }
+        *reinterpret_cast<f32x4*>(Gp) = glr;
+        *reinterpret_cast<f32x4*>(Gp + 32) = gli;
+      } else if (KIND == NK_WIRE2D) {
+        // c = conj(out) g;  g_lin = -2 s^2 Re(c) lin - j w0 c;  g_sy = -2 s^2 Re(c) sy   (modules/wire2d.py:56-67)
+        f32x4 g0, g1, g2, g3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float c_r = __builtin_fmaf(zr[ps][j], gr[j], zi[ps][j] * gi[j]);
+          const float c_i = __builtin_fmaf(zr[ps][j], gi[j], -(zi[ps][j] * gr[j]));
+          const float t = m2s2 * c_r;
+          g0[j] = __builtin_fmaf(t, ll[ps][0][j], omega * c_i);
+          g1[j] = __builtin_fmaf(t, ll[ps][1][j], -(omega * c_r));
+          g2[j] = t * ll[ps][NL - 2][j];
+          g3[j] = t * ll[ps][NL - 1][j];
+        }
+        *reinterpret_cast<f32x4*>(Gp) = g0;
+        *reinterpret_cast<f32x4*>(Gp + 32) = g1;
+        *reinterpret_cast<f32x4*>(Gp + 64) = g2;
+        *reinterpret_cast<f32x4*>(Gp + 96) = g3;
+      } else {
+        // the same forms final_bwd_kernel uses (sin'= w0 cos, gauss' = -2 s^2 lin out, relu' = [out > 0])
+        constexpr int ACT = (KIND - NK_SIREN) < 0 ? 0 : (KIND - NK_SIREN);
+        f32x4 glr, gli;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          glr[j] = real_act_bwd<ACT>(gr[j], ll[ps][0][j], zr[ps][j], omega, scale);
+          gli[j] = real_act_bwd<ACT>(gi[j], ll[ps][1][j], zi[ps][j], omega, scale);
+        }
+        *reinterpret_cast<f32x4*>(Gp) = glr;
+        *reinterpret_cast<f32x4*>(Gp + 32) = gli;
       }
-      const size_t o_ = (size_t)row * P + col[ps];
-      *reinterpret_cast<f32x4*>(g_lin + o_) = glr;
-      *reinterpret_cast<f32x4*>(g_lin + o_ + 32) = gli;
     }
   };
 #pragma unroll
-  for (int d = 0; d < PF; ++d) load_row(d, r0 + wave + 4 * d);
-  for (long long row = r0 + wave; row < r1; row += 4 * PF) {
+  for (int d = 0; d < PF; ++d) load_row(d, r0 + (wave + 4 * d) * RPW);
+  for (long long row = r0 + wave * RPW; row < r1; row += 4 * RPW * PF) {
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
-      const long long rr_ = row + 4 * d;
+      const long long rr_ = row + 4 * RPW * d;
       if (rr_ < r1) {                                   // wave-uniform
-        f32x4 zr[NPASS], zi[NPASS], lr[NPASS], li[NPASS];
+        f32x4 zr[NPASS], zi[NPASS], ll[NPASS][NL];
 #pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) { zr[ps] = nzr[d][ps]; zi[ps] = nzi[d][ps]; lr[ps] = nlr[d][ps]; li[ps] = nli[d][ps]; }
-        load_row(d, rr_ + 4 * PF);
-        process(rr_, zr, zi, lr, li);
+        for (int ps = 0; ps < NPASS; ++ps) {
+          zr[ps] = nzr[d][ps]; zi[ps] = nzi[d][ps];
+#pragma unroll
+          for (int c = 0; c < NL; ++c) ll[ps][c] = nl[d][ps][c];
+        }
+        load_row(d, rr_ + 4 * RPW * PF);
+        process(rr_, zr, zi, ll);
       }
     }
   }
@@ -594,9 +649,23 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
   // ---- combine the 4 waves: g_wf partials [O][P], bias partial [O], loss
   float* swf = sm;                                   // [4][O][P]
   float* sb = sm + 4 * O * P;                        // [4][FF_MAXO + 1]
+  if (RPW == 2) {                                    // the two half waves hold partial sums of the same columns
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          are[ps][o][j] += __shfl_xor(are[ps][o][j], 32);
+          aim[ps][o][j] += __shfl_xor(aim[ps][o][j], 32);
+        }
+      bsum[o] += __shfl_xor(bsum[o], 32);
+    }
+    lsum += __shfl_xor(lsum, 32);
+  }
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps)
-    if (live[ps])
+    if (live[ps] && sub == 0)
 #pragma unroll
       for (int o = 0; o < OT; ++o)
         if (o < O) {
@@ -622,30 +691,42 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
                                (sb[2 * (FF_MAXO + 1) + FF_MAXO] + sb[3 * (FF_MAXO + 1) + FF_MAXO]);
 }
 
-// out = nullptr: out_L is recomputed from lin_L (kvalid = number of valid complex features)
-hipError_t launch_final_fused(hipStream_t s, const float* out, const float* lin, int64_t n, int P, int O, int kvalid,
-                              const float* wf, const float* bfr, const float* target, const int64_t* idx,
+// kind: NK_*.  out = nullptr (wire only): out_L is recomputed from lin_L (kvalid = number of valid complex
+// features).  lin: [n][P] (wire2d: the 2P-wide (lin | sy) rows; relu: unused).  g_lin has the layout of lin.
+hipError_t launch_final_fused(hipStream_t s, int kind, const float* out, const float* lin, int64_t n, int P, int O,
+                              int kvalid, const float* wf, const float* bfr, const float* target, const int64_t* idx,
                               int64_t first, float weight, float omega, float scale, float* y, float* rec,
                               float* g_lin, float* part_w, float* part_b, float* loss_partial,
                               float* loss_out) {
   if (n <= 0) return hipSuccess;
   if (!final_fused_supported(P, O)) return hipErrorInvalidValue;
+  if (!out && kind != NK_WIRE) return hipErrorInvalidValue;
   const int nblk = final_bwd_blocks(n);
   const float inv = (float)(1.0 / ((double)n * (double)O));
   const size_t shm = final_fused_shm(P, O);
-#define FF_LAUNCH(NP, RC, OT)                                                                                \
-  hipLaunchKernelGGL((final_fused_kernel<NP, RC, OT>), dim3((unsigned)nblk), dim3(256), shm, s, out, lin,  \
-                     (long long)n, P, O, kvalid, wf, bfr, target, idx, (long long)first, weight * 2.f * inv, \
-                     omega, scale, y, rec, g_lin, part_w, part_b, loss_partial)
-#define FF_LAUNCH_O(NP, RC)                                                                                  \
+#define FF_LAUNCH(NP, RW, KD, RC, OT)                                                                        \
+  hipLaunchKernelGGL((final_fused_kernel<NP, KD, RC, OT, RW>), dim3((unsigned)nblk), dim3(256), shm, s, out, \
+                     lin, (long long)n, P, O, kvalid, wf, bfr, target, idx, (long long)first,                \
+                     weight * 2.f * inv, omega, scale, y, rec, g_lin, part_w, part_b, loss_partial)
+#define FF_LAUNCH_O(NP, RW, KD, RC)                                                                          \
   switch (O) {                                                                                               \
-    case 1: FF_LAUNCH(NP, RC, 1); break;                                                                     \
-    case 2: FF_LAUNCH(NP, RC, 2); break;                                                                     \
-    case 3: FF_LAUNCH(NP, RC, 3); break;                                                                     \
-    default: FF_LAUNCH(NP, RC, 4); break;                                                                    \
+    case 1: FF_LAUNCH(NP, RW, KD, RC, 1); break;                                                             \
+    case 2: case 3: FF_LAUNCH(NP, RW, KD, RC, 3); break;                                                     \
+    default: FF_LAUNCH(NP, RW, KD, RC, 4); break;                                                            \
   }
-  if (P <= 512) { if (out) { FF_LAUNCH_O(1, false); } else { FF_LAUNCH_O(1, true); } }
-  else { if (out) { FF_LAUNCH_O(2, false); } else { FF_LAUNCH_O(2, true); } }
+#define FF_LAUNCH_K(NP, RW)                                                                                  \
+  switch (kind) {                                                                                            \
+    case NK_WIRE:                                                                                            \
+      if (out) { FF_LAUNCH_O(NP, RW, NK_WIRE, false); } else { FF_LAUNCH_O(NP, RW, NK_WIRE, true); }         \
+      break;                                                                                                 \
+    case NK_WIRE2D: FF_LAUNCH_O(NP, RW, NK_WIRE2D, false); break;                                            \
+    case NK_SIREN: FF_LAUNCH_O(NP, RW, NK_SIREN, false); break;                                              \
+    case NK_GAUSS: FF_LAUNCH_O(NP, RW, NK_GAUSS, false); break;                                              \
+    case NK_RELU: FF_LAUNCH_O(NP, RW, NK_RELU, false); break;                                                \
+    default: return hipErrorInvalidValue;                                                                    \
+  }
+  if (P <= 256) { FF_LAUNCH_K(1, 2); } else if (P <= 512) { FF_LAUNCH_K(1, 1); } else { FF_LAUNCH_K(2, 1); }
+#undef FF_LAUNCH_K
 #undef FF_LAUNCH_O
 #undef FF_LAUNCH
   // the loss partials are summed by the MSE final kernel (one block)
