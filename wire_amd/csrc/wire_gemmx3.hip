@@ -998,8 +998,10 @@ hipError_t launch_gemmx3_tn(hipStream_t s, const float* G, int ldg, const float*
     }
   }
   if (tn16) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemmx3_tn16_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * X3T_STAGE);
+    // 96 KB of dynamic LDS needs the opt-in; per launch (a host-side call of about a microsecond), because the attribute
+    // belongs to the current device's copy of the function and a process may drive more than one
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemmx3_tn16_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * X3T_STAGE);
     if (attr != hipSuccess) return attr;
 #ifdef WIRE_ABLATE_TN
     static const int abl = x3_env("WIRE_TN_ABL", 0);
