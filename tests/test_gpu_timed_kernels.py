@@ -360,7 +360,7 @@ def test_fused_step_equals_autograd_path_every_kind(case):
     ref_loss = ((pix - target.to(DEV)[perm]) ** 2).mean()
     ref_loss.backward()
     torch.cuda.synchronize()
-    assert abs(float(loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
+    assert abs(float(loss.item()) - float(ref_loss.item())) <= 1e-5 * abs(float(ref_loss.item()))
     e_y = relmax(rec.cpu().numpy()[perm.numpy()], pix.detach().cpu().numpy())
     assert e_y <= 1e-5, f"{case} y {e_y:.2e}"
     names = [k for k in model.state_dict().keys() if "omega_0" not in k and "scale_0" not in k]
