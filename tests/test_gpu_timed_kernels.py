@@ -284,7 +284,8 @@ def test_fused_trainer_step_gradients_vs_fp64_oracle(case):
             within_ref(relmax(mine, ref), relmax(ref32, ref), f"{tag} grad {name}")
 
 
-def test_recompute_out_is_bit_identical():
+@pytest.mark.parametrize("nonlin", ["wire", "wire2d"])
+def test_recompute_out_is_bit_identical(nonlin):
     """Knob "recompute_out" (default 1; wire_api.hip): on the 16x16x32 kernels the data-gradient epilogues and the
     fused final stage evaluate out = exp(j w0 lin - s0^2 |lin|^2) again from the stored lin (modules/wire.py:90-93)
     instead of reading the stored out, and the last hidden layer stores no out at all.  Same lean form as the forward
@@ -297,7 +298,13 @@ def test_recompute_out_is_bit_identical():
     for knob in (0, 1):
         _lib.check(L.wire_tune_set(b"recompute_out", knob))
         try:
-            model = _wire_model(4, 20.0, 30.0, hf=363, D=2, O=3, seed=3)
+            if nonlin == "wire":
+                model = _wire_model(4, 20.0, 30.0, hf=363, D=2, O=3, seed=3)
+            else:                                      # modules/wire2d.py:56-67 (out = exp(j w0 lin - s0^2 (|lin|^2 + |sy|^2)))
+                from wire_amd.modules import models
+                torch.manual_seed(3)
+                model = models.get_INR(nonlin="wire2d", in_features=2, out_features=3, hidden_features=256,
+                                       hidden_layers=3, first_omega_0=10.0, hidden_omega_0=10.0, scale=10.0).to(DEV)
             g = torch.Generator().manual_seed(5)
             N = 128 * 128
             target = torch.rand(N, 3, generator=g)

@@ -198,30 +198,36 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
 #pragma unroll
       for (int hr = 0; hr < 2; ++hr) {
         const int row = m_w + 16 * rb + 8 * hr + rr;
-        f32x4 u, v, pp, qq, o_re, o_im;
+        f32x4 u, v, pp, qq;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           u[q] = part[0][hr][q] + bv[0][q];
           v[q] = part[1][hr][q] + bv[1][q];
           pp[q] = part[2][hr][q] + bv[2][q];
           qq[q] = part[3][hr][q] + bv[3][q];
-          float a, b;
-          gabor2d_fwd_lean(u[q], v[q], pp[q], qq[q], ep.omega, ep.scale, a, b);
-          const bool valid = f0 + q < ep.kvalid;
-          o_re[q] = valid ? a : 0.f;
-          o_im[q] = valid ? b : 0.f;
         }
-        if (row < M) {
-          if (ep.o0) {
-            float* Lp = ep.o0 + (size_t)row * ep.ld0 + n_w + cq;
-            *reinterpret_cast<f32x4*>(Lp) = u;
-            *reinterpret_cast<f32x4*>(Lp + 32) = v;
-            *reinterpret_cast<f32x4*>(Lp + 64) = pp;
-            *reinterpret_cast<f32x4*>(Lp + 96) = qq;
+        if (ep.o0 && row < M) {
+          float* Lp = ep.o0 + (size_t)row * ep.ld0 + n_w + cq;
+          *reinterpret_cast<f32x4*>(Lp) = u;
+          *reinterpret_cast<f32x4*>(Lp + 32) = v;
+          *reinterpret_cast<f32x4*>(Lp + 64) = pp;
+          *reinterpret_cast<f32x4*>(Lp + 96) = qq;
+        }
+        if (ep.o1) {                                              // null: last hidden layer of a fused training step
+          f32x4 o_re, o_im;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float a, b;
+            gabor2d_fwd_lean(u[q], v[q], pp[q], qq[q], ep.omega, ep.scale, a, b);
+            const bool valid = f0 + q < ep.kvalid;
+            o_re[q] = valid ? a : 0.f;
+            o_im[q] = valid ? b : 0.f;
           }
-          float* Op = ep.o1 + (size_t)row * ep.ld1 + oc;
-          *reinterpret_cast<f32x4*>(Op) = o_re;
-          *reinterpret_cast<f32x4*>(Op + 32) = o_im;
+          if (row < M) {
+            float* Op = ep.o1 + (size_t)row * ep.ld1 + oc;
+            *reinterpret_cast<f32x4*>(Op) = o_re;
+            *reinterpret_cast<f32x4*>(Op + 32) = o_im;
+          }
         }
       }
     }
@@ -259,15 +265,28 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
         for (int hr = 0; hr < 2; ++hr) {
           int row = m_w + 16 * rb + 8 * hr + rr;
           row = row < M ? row : M - 1;
-          const float* Op = ep.i1 + (size_t)row * ep.ld1 + c0;
-          pr[hr] = *reinterpret_cast<const f32x4*>(Op);
-          pi[hr] = *reinterpret_cast<const f32x4*>(Op + 32);
+          const bool recompute = EPI == EPI_GABOR2D_BWD && ep.recompute_out != 0;
+          if (!recompute) {
+            const float* Op = ep.i1 + (size_t)row * ep.ld1 + c0;
+            pr[hr] = *reinterpret_cast<const f32x4*>(Op);
+            pi[hr] = *reinterpret_cast<const f32x4*>(Op + 32);
+          }
           if constexpr (EPI == EPI_GABOR2D_BWD) {
             const float* Lp = ep.i0 + (size_t)row * ep.ld0 + lc;
             u[hr] = *reinterpret_cast<const f32x4*>(Lp);
             v[hr] = *reinterpret_cast<const f32x4*>(Lp + 32);
             pp[hr] = *reinterpret_cast<const f32x4*>(Lp + 64);
             qq[hr] = *reinterpret_cast<const f32x4*>(Lp + 96);
+            if (recompute) {                                      // out = act(lin, sy) again: the forward's lean form
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                float a, b;
+                gabor2d_fwd_lean(u[hr][q], v[hr][q], pp[hr][q], qq[hr][q], ep.omega, ep.scale, a, b);
+                const bool valid = f0 + q < ep.kvalid;
+                pr[hr][q] = valid ? a : 0.f;
+                pi[hr][q] = valid ? b : 0.f;
+              }
+            }
           } else {
             float x[4] = {0.f, 0.f, 0.f, 0.f};
             for (int d = 0; d < ep.D; ++d) x[d] = ep.coords[(size_t)row * ep.D + d];

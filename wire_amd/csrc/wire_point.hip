@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
     const int64_t* __restrict__ idx, long long first, float gscale, float omega, float scale,
     float* __restrict__ y, float* __restrict__ rec, float* __restrict__ g_lin, float* __restrict__ part_w,
     float* __restrict__ part_b, float* __restrict__ loss_partial) {
-  static_assert(!RECOMP || KIND == NK_WIRE, "recompute exists for the wire activation only");
+  static_assert(!RECOMP || KIND == NK_WIRE || KIND == NK_WIRE2D, "recompute exists for the Gabor activations only");
   static_assert(RPW == 1 || (RPW == 2 && NPASS == 1), "two rows per wave slot: one pass of at most 256 columns");
   constexpr int RL = 64 / RPW;                         // lanes of one row
   constexpr bool HAS_LIN = (KIND != NK_RELU);          // relu: lin is never stored (lin > 0 <=> out > 0)
@@ -530,7 +530,10 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float a_, b_;
-          gabor_fwd_lean(ll[ps][0][j], ll[ps][1][j], omega, w0l2e, ns2l2e, a_, b_);
+          if (KIND == NK_WIRE2D)
+            gabor2d_fwd_lean(ll[ps][0][j], ll[ps][1][j], ll[ps][NL - 2][j], ll[ps][NL - 1][j], omega, scale, a_, b_);
+          else
+            gabor_fwd_lean(ll[ps][0][j], ll[ps][1][j], omega, w0l2e, ns2l2e, a_, b_);
           const bool valid = live[ps] && f0 + j < kvalid;          // pad features are 0
           zr[ps][j] = valid ? a_ : 0.f;
           zi[ps][j] = valid ? b_ : 0.f;
@@ -700,7 +703,7 @@ hipError_t launch_final_fused(hipStream_t s, int kind, const float* out, const f
                               float* loss_out) {
   if (n <= 0) return hipSuccess;
   if (!final_fused_supported(P, O)) return hipErrorInvalidValue;
-  if (!out && kind != NK_WIRE) return hipErrorInvalidValue;
+  if (!out && kind != NK_WIRE && kind != NK_WIRE2D) return hipErrorInvalidValue;
   const int nblk = final_bwd_blocks(n);
   const float inv = (float)(1.0 / ((double)n * (double)O));
   const size_t shm = final_fused_shm(P, O);
@@ -719,7 +722,9 @@ hipError_t launch_final_fused(hipStream_t s, int kind, const float* out, const f
     case NK_WIRE:                                                                                            \
       if (out) { FF_LAUNCH_O(NP, RW, NK_WIRE, false); } else { FF_LAUNCH_O(NP, RW, NK_WIRE, true); }         \
       break;                                                                                                 \
-    case NK_WIRE2D: FF_LAUNCH_O(NP, RW, NK_WIRE2D, false); break;                                            \
+    case NK_WIRE2D:                                                                                          \
+      if (out) { FF_LAUNCH_O(NP, RW, NK_WIRE2D, false); } else { FF_LAUNCH_O(NP, RW, NK_WIRE2D, true); }     \
+      break;                                                                                                 \
     case NK_SIREN: FF_LAUNCH_O(NP, RW, NK_SIREN, false); break;                                              \
     case NK_GAUSS: FF_LAUNCH_O(NP, RW, NK_GAUSS, false); break;                                              \
     case NK_RELU: FF_LAUNCH_O(NP, RW, NK_RELU, false); break;                                                \
