@@ -277,7 +277,8 @@ int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* 
  * "x3_h16" (default 15): the v_mfma_f32_16x16x32_bf16 edition (wire_gemmx3h.hip) of the NT GEMMs at M >= 4096:
  *     bit 0 wire forward, bit 1 wire data gradient, bit 2 siren / gauss / relu, bit 3 wire2d; 0 = the 32x32x16 kernels.
  * "x3_tn16" (default 1): the weight-gradient (TN) GEMM of the split-bf16 family runs its 256 x 256-tile
- *     v_mfma_f32_16x16x32_bf16 kernel when both padded widths are multiples of 256; 0 = the 128 x 128 kernel.
+ *     v_mfma_f32_16x16x32_bf16 kernel when both padded widths are multiples of 256 (up to 256 row splits); 0 = the
+ *     128 x 128 kernel.
  * "recompute_out" (default 1): on the 16x16x32 kernels the backward of a wire net evaluates out = act(lin) again
  *     (same lean form, same bits) instead of reading it back: data-gradient epilogues, the fused final stage of
  *     wire_train_fwd_bwd (whose last hidden layer then does not store out at all).  0 = read the stored activations.

@@ -30,7 +30,7 @@ static float* dalloc(size_t n, unsigned seed, float scale) {
 static void run_sum(int mode, const float* G, const float* Z, int64_t n, int P, std::vector<double>& W,
                     std::vector<double>& B, int* S_out) {
   gemmx3_tune_set("x3_tn16", mode);
-  const int S = gemmx3_tn_splits(n, P, P, 192);
+  const int S = gemmx3_tn_splits(n, P, P, 256);
   float* slab; CK(hipMalloc(&slab, (size_t)S * P * P * 4));
   float* bslab; CK(hipMalloc(&bslab, (size_t)S * P * 4));
   CK(hipMemset(slab, 0xff, (size_t)S * P * P * 4));
@@ -91,12 +91,12 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const double flop = 2.0 * N * P * P;
   double tsum[2] = {0, 0}; int Ss[2] = {0, 0};
-  float* slab; CK(hipMalloc(&slab, (size_t)192 * P * P * 4));
-  float* bslab; CK(hipMalloc(&bslab, (size_t)192 * P * 4));
+  float* slab; CK(hipMalloc(&slab, (size_t)256 * P * P * 4));
+  float* bslab; CK(hipMalloc(&bslab, (size_t)256 * P * 4));
   for (int r = 0; r < rounds + 1; ++r)
     for (int mode = 0; mode < 2; ++mode) {
       gemmx3_tune_set("x3_tn16", mode);
-      const int S = gemmx3_tn_splits(N, P, P, 192);
+      const int S = gemmx3_tn_splits(N, P, P, 256);
       Ss[mode] = S;
       CK(hipEventRecord(e0, 0));
       for (int q = 0; q < 4; ++q) CK(launch_gemmx3_tn(0, G, P, Z, P, N, P, P, S, slab, bslab));

@@ -250,7 +250,7 @@ ScratchLayout scratch_layout(const Plan& p, int64_t n) {
   const int64_t pn = p.first_gemm && p.Pin0 > p.P ? p.Pin0 : p.P;
   // slabs sized for the largest split count of the three GEMM families (flag-independent scratch size)
   // (the split-bf16 kernel may split finer: narrow nets have few tiles and would otherwise leave CUs idle)
-  const int s_x3 = gemmx3_tn_splits_max(n, p.Pl, (int)pn, 192), s_4m = gemm_tn_splits(n, p.Pl, (int)pn, 64);
+  const int s_x3 = gemmx3_tn_splits_max(n, p.Pl, (int)pn, 256), s_4m = gemm_tn_splits(n, p.Pl, (int)pn, 64);
   const int s_max = s_x3 > s_4m ? s_x3 : s_4m;
   if (p.m3) {
     s.S = gemm3m_tn_splits(n, p.Kp, p.Kp, 64);

@@ -931,11 +931,9 @@ __global__ __launch_bounds__(512, 2) void gemmx3_tn16_kernel(
 // SAME number of resident workgroups each (3, else 2, else 1) -- e.g. K = 181 (9 tiles): 56 splits = 504
 // workgroups = 2 per CU, where 64 splits (576 workgroups) would leave a quarter of the CUs with 3 and the
 // rest with 2, and the launch waits for the loaded ones.
-// a single 256 x 256 tile (siren / gauss / relu at 256 features) cannot fill the chip within the split cap and
-// measured 0 - 2 % slower than the 128 x 128 kernel: two tiles or more
-static bool tn16_applies(int Pm, int Pn, int mode) {
-  return mode != 0 && Pm % 256 == 0 && Pn % 256 == 0 && (Pm / 256) * (Pn / 256) >= 2;
-}
+// (a single 256 x 256 tile -- siren / gauss / relu at 256 features -- needs 256 row splits to fill the chip: callers
+// size their slabs for up to 256)
+static bool tn16_applies(int Pm, int Pn, int mode) { return mode != 0 && Pm % 256 == 0 && Pn % 256 == 0; }
 
 static int tn_splits_for(int64_t n, int Pm, int Pn, int max_splits, bool tn16) {
   int s = 0;

@@ -32,7 +32,7 @@ struct LayerWs {
 // weight-gradient row splits of a family (the workspace is sized for the largest: its size must not depend on
 // the tuning flags)
 inline int layer_splits(int fam, int64_t n, int Pout, int Pin) {
-  if (fam == FAM_X3) return gemmx3_tn_splits(n, Pout, Pin, 192);
+  if (fam == FAM_X3) return gemmx3_tn_splits(n, Pout, Pin, 256);
   if (fam == FAM_3M) return gemm3m_tn_splits(n, Pout / 2, Pin / 2, 64);
   return gemm_tn_splits(n, Pout, Pin, 64);
 }
@@ -47,7 +47,7 @@ LayerWs layer_ws(int64_t n, int in, int out) {
   int64_t slab_f = 0, bslab_f = 0;
   auto fit = [&](int Pm, int Pn) {
     for (int fam = FAM_4M; fam <= FAM_X3; ++fam) {
-      const int64_t S = fam == FAM_X3 ? gemmx3_tn_splits_max(n, Pm, Pn, 192) : layer_splits(fam, n, Pm, Pn);
+      const int64_t S = fam == FAM_X3 ? gemmx3_tn_splits_max(n, Pm, Pn, 256) : layer_splits(fam, n, Pm, Pn);
       const int64_t sl = fam == FAM_3M ? S * 3 * (Pm / 2) * (Pn / 2) : S * Pm * Pn;
       if (sl > slab_f) slab_f = sl;
       if (S * Pm > bslab_f) bslab_f = S * Pm;
@@ -357,7 +357,7 @@ Layer2dWs layer2d_ws(int64_t n, int in, int out) {
   w.Pout = rup(2 * out, 64);
   w.ldu = w.Pout / 2;
   w.S = gemm_tn_splits(n, 2 * w.Pout, w.Pin, 64);
-  const int64_t s_max = std::max<int64_t>(w.S, gemmx3_tn_splits_max(n, 2 * w.Pout, w.Pin, 192));
+  const int64_t s_max = std::max<int64_t>(w.S, gemmx3_tn_splits_max(n, 2 * w.Pout, w.Pin, 256));
   int64_t off = 0;
   auto take = [&](int64_t cnt) { int64_t o = off; off += rup64(cnt, 64); return o; };
   w.xb = take(n * w.Pin);
