@@ -334,6 +334,15 @@ KIND_CASES = {
     "siren_big": (dict(nonlin="siren", hidden_features=256, first_omega_0=30.0, hidden_omega_0=30.0), (96, 64)),
     "wire2d_big": (dict(nonlin="wire2d", hidden_features=181, first_omega_0=5.0, hidden_omega_0=5.0, scale=4.0),
                    (96, 64)),
+    # >= 4096 rows, not a multiple of 256: the 16x16x32 kernels with recompute_out, the 256 x 256 weight-gradient
+    # tiles and the fused final stage, all with a ragged last tile / block
+    "wire_k256_ragged": (dict(nonlin="wire", hidden_features=363, first_omega_0=7.0, hidden_omega_0=7.0, scale=6.0),
+                         (67, 71)),
+    "wire_k128_ragged": (dict(nonlin="wire", hidden_features=181, first_omega_0=7.0, hidden_omega_0=7.0, scale=6.0),
+                         (67, 71)),
+    "wire2d_ragged": (dict(nonlin="wire2d", hidden_features=256, first_omega_0=5.0, hidden_omega_0=5.0, scale=4.0),
+                      (67, 71)),
+    "siren_ragged": (dict(nonlin="siren", hidden_features=256, first_omega_0=30.0, hidden_omega_0=30.0), (67, 71)),
 }
 
 
