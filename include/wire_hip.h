@@ -282,6 +282,8 @@ int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* 
  * "recompute_out" (default 1): on the 16x16x32 kernels the backward of a wire net evaluates out = act(lin) again
  *     (same lean form, same bits) instead of reading it back: data-gradient epilogues, the fused final stage of
  *     wire_train_fwd_bwd (whose last hidden layer then does not store out at all).  0 = read the stored activations.
+ * "first_sums" (default 1): wire nets on the 16x16x32 kernels -- the epilogue of the last data-gradient GEMM forms the
+ *     first layer's per-tile gradient sums itself instead of storing g_u for a separate reduction pass.
  * "x3_glds" (default 0): 1 / 2 = LDS-DMA 32x32x16 editions of the split-bf16 NT GEMM at M >= 4096
  *     (wire_gemmx3g.hip).  All editions give bit-identical GEMM results.
  * Neither buffer sizes (wire_packed_floats, wire_act_bytes, wire_bwd_scratch_bytes) nor

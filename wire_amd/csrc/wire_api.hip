@@ -101,6 +101,7 @@ extern "C" int wire_prof_read(double* ms_total, int64_t* launches, double* flops
 // wire training step on the 16 x 16 x 32 kernels: backward passes evaluate out = act(lin) again instead of reading it
 // (the data-gradient epilogues and the fused final stage), and the last hidden layer does not store out at all
 static int g_recompute_out = [] { const char* v = getenv("WIRE_RECOMPUTE_OUT"); return v ? atoi(v) : 1; }();
+static int g_first_sums = [] { const char* v = getenv("WIRE_FIRST_SUMS"); return v ? atoi(v) : 1; }();
 static int g_complex_3m = 1;   // wire: 3-multiplication complex GEMMs on the fp32 MFMA (wire_gemm3m.hip)
 static int env_flag(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -127,6 +128,7 @@ extern "C" int wire_tune_set(const char* key, int value) {
   if (!strcmp(key, "complex_3m")) { g_complex_3m = value ? 1 : 0; return WIRE_OK; }
   if (!strcmp(key, "split_bf16")) { g_split_bf16 = value ? 1 : 0; return WIRE_OK; }
   if (!strcmp(key, "recompute_out")) { g_recompute_out = value ? 1 : 0; return WIRE_OK; }
+  if (!strcmp(key, "first_sums")) { g_first_sums = value ? 1 : 0; return WIRE_OK; }
   if (gemm_tune_set(key, value) == 0) return WIRE_OK;
   if (gemmx3_tune_set(key, value) == 0) return WIRE_OK;
   return fail(WIRE_ERR_ARG, "unknown tuning key or bad value: %s=%d", key, value);
@@ -482,6 +484,8 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
   auto lin_l = [&](int l) { return l == 0 ? A + a.lin0 : A + a.lin1 + (int64_t)(l - 1) * n * p.Pl; };
   float* gcur = Sx + sc.ga;
   float* gnext = Sx + sc.gb;
+  const bool first_sums = g_first_sums && p.kind == WIRE_KIND_WIRE && p.x3 && p.L >= 1 &&
+                          gemmx3_nt_is_h16(EPI_GABOR_BWD_FIRST, n);
 
   // ---- final linear + activation gradient of layer L
   const int nbf = final_bwd_blocks(n);
@@ -557,6 +561,9 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
       epi = (p.kind == WIRE_KIND_WIRE) ? EPI_GABOR_BWD_FIRST : EPI_GABOR2D_BWD_FIRST;
       ep.omega = p.w1;
       ep.coords = coords; ep.D = p.D; ep.ldu = p.ldu; ep.o0 = Sx + sc.gu;
+      // wire on the 16 x 16 x 32 kernel: its epilogue sums g_u [x | 1] per 256-row tile itself (the first layer's weight
+      // and bias gradient partials) instead of storing g_u for a separate pass
+      if (first_sums) { ep.cr_partial = Sx + sc.crp; ep.cr_C = p.K; }
       ep.W0 = packed + first_native_off(p, 0); ep.b0 = packed + first_native_off(p, 1);
       if (p.per_layer == 4) { ep.W0b = packed + first_native_off(p, 2); ep.b0b = packed + first_native_off(p, 3); }
     }
@@ -575,7 +582,9 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
   ProfScope ps(s, 3, 0);
   if (p.cplx) {
     const float* gu = Sx + sc.gu;
-    if (p.kind == WIRE_KIND_WIRE) {
+    if (p.kind == WIRE_KIND_WIRE && first_sums) {
+      HIPCHK(launch_colreduce_final(s, p.K, p.D, n, Sx + sc.crp, (float*)grads[0], (float*)grads[1]));
+    } else if (p.kind == WIRE_KIND_WIRE) {
       HIPCHK(launch_colreduce(s, gu, p.ldu, p.K, coords, p.D, n, Sx + sc.crp, (float*)grads[0],
                               (float*)grads[1]));
     } else {

@@ -104,7 +104,7 @@ WIRE_DEVINL void h_pair_rows(const f32x4& X, const f32x4& Y, f32x4& Xp, f32x4& Y
 
 template <int EPI>
 WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const int M, const int m_w, const int n_w,
-                            const int Nc, const int lane) {
+                            const int Nc, const int lane, unsigned char* lds, const int wave, const int rt) {
   const int rr = lane & 7, ch = (lane >> 3) & 1, g = lane >> 4;
   const int cq = 16 * ch + 4 * g;                                 // this lane's first column inside a 32-column span
   if constexpr (EPI == EPI_STORE) {
@@ -344,6 +344,11 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
       const int f0 = ((c0 >> 6) << 5) + (c0 & 31);                // ... = features f0 .. f0 + 3
       f32x4 b_re = {0.f, 0.f, 0.f, 0.f}, b_im = b_re;
       float w[4][4], bb[4];
+      float crs[4][5];                                            // BWD_FIRST with cr_partial: sums of g_u [x | 1]
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int d = 0; d < 5; ++d) crs[q][d] = 0.f;
       if constexpr (EPI == EPI_GABOR_FWD) {
         b_re = *reinterpret_cast<const f32x4*>(ep.bias + c0);
         b_im = *reinterpret_cast<const f32x4*>(ep.bias + c0 + 32);
@@ -462,9 +467,58 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
                 const float v = gabor_bwd_real(are[hr][q], aim[hr][q], u, pr[q], pi[q], w0, m2s2);
                 gu[q] = f0 + q < ep.kvalid ? v : 0.f;
               }
-              *reinterpret_cast<f32x4*>(ep.o0 + (size_t)row * ep.ldu + f0) = gu;
+              if (ep.cr_partial) {
+                // first-layer gradient sums of this lane's rows: g_u [x | 1] (what colreduce_kernel would form from
+                // the stored g_u -- which is then never written)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                  for (int d = 0; d < 4; ++d) crs[q][d] = __builtin_fmaf(gu[q], x[d], crs[q][d]);
+                  crs[q][4] += gu[q];
+                }
+              } else {
+                *reinterpret_cast<f32x4*>(ep.o0 + (size_t)row * ep.ldu + f0) = gu;
+              }
             }
           }
+        }
+      }
+      if constexpr (EPI == EPI_GABOR_BWD_FIRST) {
+        if (ep.cr_partial) {
+          // sum over the 8 row lanes of each 16-lane row (lanes differing in bits 0-2), then over the 4 waves through LDS
+          // (the main loop is over: every wave has passed its last barrier, the stage buffers are free)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int d = 0; d < 5; ++d) {
+              float v = crs[q][d];
+              v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+              crs[q][d] = v;
+            }
+          float* red = reinterpret_cast<float*>(lds);            // [4 waves][64 features][5]
+          const int fl = 32 * G + cq;                             // feature inside the tile's 64: 32 G + 16 ch + 4 g (+ q)
+          if (rr == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int d = 0; d < 5; ++d) red[(wave * 64 + fl + q) * 5 + d] = crs[q][d];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int d = 0; d < 5; ++d) crs[q][d] = 0.f;
+        }
+      }
+    }
+    if constexpr (EPI == EPI_GABOR_BWD_FIRST) {
+      if (ep.cr_partial) {
+        __syncthreads();
+        const float* red = reinterpret_cast<const float*>(lds);
+        const int fbase = (n_w >> 6) << 5;                        // first complex feature of this 128-column tile
+        for (int e = threadIdx.x; e < 64 * 5; e += 256) {
+          const int f = e / 5, d = e - 5 * f;
+          const float v = (red[e] + red[64 * 5 + e]) + (red[2 * 64 * 5 + e] + red[3 * 64 * 5 + e]);
+          if (fbase + f < ep.cr_C) ep.cr_partial[((size_t)rt * ep.cr_C + fbase + f) * 5 + d] = v;
         }
       }
     }
@@ -607,7 +661,7 @@ __global__ __launch_bounds__(256, 2) void gemmx3h_nt_kernel(const float* __restr
     __builtin_amdgcn_sched_barrier(0);
     buf ^= 1;
   }
-  h_epilogue<EPI>(acc, ep, M, m_base + wave * 64, n_base, Nc, lane);
+  h_epilogue<EPI>(acc, ep, M, m_base + wave * 64, n_base, Nc, lane, smem, wave, rt);
 }
 
 template <int EPI>

@@ -982,17 +982,24 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __res
   }
 }
 
+// stage 2 alone: partial[colreduce_blocks(n)][C][5] already holds the per-256-row sums (written by the data-gradient
+// epilogue of wire_gemmx3h.hip, GemmEpiParams::cr_partial)
+hipError_t launch_colreduce_final(hipStream_t s, int C, int D, int64_t n, float* partial, float* gW0, float* gb0) {
+  if (D > 4) return hipErrorInvalidValue;
+  const int nblk = colreduce_blocks(n);
+  float* p2 = partial + (size_t)nblk * C * 5;            // slack reserved by colreduce_partial_floats
+  const int nb = prereduce(s, partial, nblk, C * 5, p2);
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3(cdiv(C, 64)), dim3(256), 0, s, nb == nblk ? partial : p2, nb,
+                     C, D, gW0, gb0);
+  return hipGetLastError();
+}
 hipError_t launch_colreduce(hipStream_t s, const float* G, int ldg, int C, const float* x, int D,
                             int64_t n, float* partial, float* gW0, float* gb0) {
   if (D > 4 || (ldg & 3)) return hipErrorInvalidValue;
   const int nblk = colreduce_blocks(n);
   dim3 grid((unsigned)nblk, cdiv(C, 256));
   hipLaunchKernelGGL(colreduce_kernel, grid, dim3(256), 0, s, G, ldg, C, x, D, (long long)n, partial);
-  float* p2 = partial + (size_t)nblk * C * 5;            // slack reserved by colreduce_partial_floats
-  const int nb = prereduce(s, partial, nblk, C * 5, p2);
-  hipLaunchKernelGGL(colreduce_final_kernel, dim3(cdiv(C, 64)), dim3(256), 0, s, nb == nblk ? partial : p2, nb,
-                     C, D, gW0, gb0);
-  return hipGetLastError();
+  return launch_colreduce_final(s, C, D, n, partial, gW0, gb0);
 }
 
 // ===========================================================================
