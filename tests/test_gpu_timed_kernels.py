@@ -387,3 +387,31 @@ def test_fused_step_equals_autograd_path_every_kind(case):
         mine = flat[off:off + ref.numel()]
         e = relmax(mine.cpu().numpy(), ref.cpu().numpy())
         assert e <= 2e-5, f"{case} grad {name}: {e:.2e}"
+
+
+def test_first_layer_sums_in_epilogue_agree_with_separate_pass():
+    """Knob "first_sums" (default 1): the first layer's weight / bias gradient g_u^T [x | 1] (autograd of
+    modules/wire.py:89 with is_first) is summed per 256-row tile inside the last data-gradient epilogue instead of a
+    separate pass over a stored g_u.  Another summation order, so agreement is to fp32 round-off; ragged row count."""
+    from wire_amd import _lib
+    from wire_amd.trainer import FusedTrainer
+    L = _lib.lib()
+    res = []
+    for knob in (0, 1):
+        _lib.check(L.wire_tune_set(b"first_sums", knob))
+        try:
+            model = _wire_model(2, 20.0, 30.0, hf=363, D=2, O=3, seed=4)
+            g = torch.Generator().manual_seed(6)
+            N = 67 * 71
+            target = torch.rand(N, 3, generator=g)
+            tr = FusedTrainer(model, (67, 71), target, lr=0.0)
+            tr.step(torch.randperm(N, generator=g).to(DEV))
+            torch.cuda.synchronize()
+            res.append(tr.flat_grad.clone())
+        finally:
+            _lib.check(L.wire_tune_set(b"first_sums", 1))
+    n0 = 256 * 2 * 2 + 256 * 2                        # first layer: complex W [256, 2] and b [256] as real pairs
+    a, b = res[0].cpu().numpy(), res[1].cpu().numpy()
+    assert np.abs(a[:n0]).max() > 0
+    assert relmax(b[:n0], a[:n0]) <= 5e-6
+    assert np.array_equal(a[n0:], b[n0:])              # every other gradient is untouched by the knob
