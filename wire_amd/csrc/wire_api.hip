@@ -564,6 +564,8 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
       // wire on the 16 x 16 x 32 kernel: its epilogue sums g_u [x | 1] per 256-row tile itself (the first layer's weight
       // and bias gradient partials) instead of storing g_u for a separate pass
       if (first_sums) { ep.cr_partial = Sx + sc.crp; ep.cr_C = p.K; }
+      // (and re-evaluates out_0 from the u it recomputes anyway: first_fwd_kernel's own form, the same bits)
+      ep.recompute_out = g_recompute_out && p.x3 && p.kind == WIRE_KIND_WIRE && gemmx3_nt_is_h16(EPI_GABOR_BWD_FIRST, n);
       ep.W0 = packed + first_native_off(p, 0); ep.b0 = packed + first_native_off(p, 1);
       if (p.per_layer == 4) { ep.W0b = packed + first_native_off(p, 2); ep.b0b = packed + first_native_off(p, 3); }
     }

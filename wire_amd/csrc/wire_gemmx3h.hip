@@ -456,14 +456,25 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
             if (row < M) {
               float x[4] = {0.f, 0.f, 0.f, 0.f};
               for (int d = 0; d < ep.D; ++d) x[d] = ep.coords[(size_t)row * ep.D + d];
-              const float* Op = ep.i1 + (size_t)row * ep.ld1 + c0;
-              const f32x4 pr = *reinterpret_cast<const f32x4*>(Op), pi = *reinterpret_cast<const f32x4*>(Op + 32);
+              // out_0: read back, or (recompute_out) evaluated again from u with first_fwd_kernel's own form -- same
+              // fmaf chain for u, same gabor_fwd_real: the same bits, 8 bytes per element less
+              f32x4 pr = {0.f, 0.f, 0.f, 0.f}, pi = pr;
+              if (!ep.recompute_out) {
+                const float* Op = ep.i1 + (size_t)row * ep.ld1 + c0;
+                pr = *reinterpret_cast<const f32x4*>(Op);
+                pi = *reinterpret_cast<const f32x4*>(Op + 32);
+              }
               f32x4 gu;
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 float u = bb[q];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) u = __builtin_fmaf(x[d], w[q][d], u);
+                if (ep.recompute_out) {
+                  float a, b;
+                  gabor_fwd_real(u, w0, ep.scale, a, b);
+                  pr[q] = a; pi[q] = b;
+                }
                 const float v = gabor_bwd_real(are[hr][q], aim[hr][q], u, pr[q], pi[q], w0, m2s2);
                 gu[q] = f0 + q < ep.kvalid ? v : 0.f;
               }
