@@ -279,7 +279,7 @@ int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* 
  * "x3_tn16" (default 1): the weight-gradient (TN) GEMM of the split-bf16 family runs its 256 x 256-tile
  *     v_mfma_f32_16x16x32_bf16 kernel when both padded widths are multiples of 256 (up to 256 row splits); 0 = the
  *     128 x 128 kernel.
- * "recompute_out" (default 1): on the 16x16x32 kernels the backward of a wire net evaluates out = act(lin) again
+ * "recompute_out" (default 1): on the 16x16x32 kernels the backward of a wire / wire2d / siren / gauss net evaluates out = act(lin) again
  *     (same lean form, same bits) instead of reading it back: data-gradient epilogues, the fused final stage of
  *     wire_train_fwd_bwd (whose last hidden layer then does not store out at all).  0 = read the stored activations.
  * "first_sums" (default 1): wire nets on the 16x16x32 kernels -- the epilogue of the last data-gradient GEMM forms the

@@ -284,7 +284,7 @@ def test_fused_trainer_step_gradients_vs_fp64_oracle(case):
             within_ref(relmax(mine, ref), relmax(ref32, ref), f"{tag} grad {name}")
 
 
-@pytest.mark.parametrize("nonlin", ["wire", "wire2d"])
+@pytest.mark.parametrize("nonlin", ["wire", "wire2d", "siren", "gauss"])
 def test_recompute_out_is_bit_identical(nonlin):
     """Knob "recompute_out" (default 1; wire_api.hip): on the 16x16x32 kernels the data-gradient epilogues and the
     fused final stage evaluate out = exp(j w0 lin - s0^2 |lin|^2) again from the stored lin (modules/wire.py:90-93)
@@ -303,7 +303,7 @@ def test_recompute_out_is_bit_identical(nonlin):
             else:                                      # modules/wire2d.py:56-67 (out = exp(j w0 lin - s0^2 (|lin|^2 + |sy|^2)))
                 from wire_amd.modules import models
                 torch.manual_seed(3)
-                model = models.get_INR(nonlin="wire2d", in_features=2, out_features=3, hidden_features=256,
+                model = models.get_INR(nonlin=nonlin, in_features=2, out_features=3, hidden_features=256,
                                        hidden_layers=3, first_omega_0=10.0, hidden_omega_0=10.0, scale=10.0).to(DEV)
             g = torch.Generator().manual_seed(5)
             N = 128 * 128

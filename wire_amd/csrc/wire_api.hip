@@ -556,7 +556,8 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
       ep.omega = (l - 1 == 0) ? p.w1 : p.w;
       ep.i0 = lin_l(l - 1); ep.o0 = gnext; ep.ld0 = p.Pl;
       // hidden Gabor layer whose forward ran the lean 16 x 16 x 32 epilogue: out = act(lin) again, 8 B / element less
-      ep.recompute_out = g_recompute_out && p.x3 && p.cplx && gemmx3_nt_is_h16(epi_fwd(p.kind), n);
+      // (real nets: only below a hidden layer -- the first layer's out comes from first_fwd_kernel's precise form)
+      ep.recompute_out = g_recompute_out && p.x3 && (p.cplx || l - 1 >= 1) && gemmx3_nt_is_h16(epi_fwd(p.kind), n);
     } else {
       epi = (p.kind == WIRE_KIND_WIRE) ? EPI_GABOR_BWD_FIRST : EPI_GABOR2D_BWD_FIRST;
       ep.omega = p.w1;
@@ -646,7 +647,7 @@ extern "C" int wire_train_fwd_bwd(void* stream, const wire_net_desc* d, const fl
   }
   // with layer L on the 16 x 16 x 32 forward kernel (lean epilogue) the final stage evaluates out_L from lin_L itself,
   // bit for bit what that epilogue would have stored: out_L is neither written nor read (1 GB less HBM traffic)
-  const bool recomp = g_recompute_out && p.x3 && p.cplx && gemmx3_nt_is_h16(epi_fwd(p.kind), n);
+  const bool recomp = g_recompute_out && p.x3 && p.kind != WIRE_KIND_RELU && gemmx3_nt_is_h16(epi_fwd(p.kind), n);
   if (int rc = mlp_fwd_core(stream, p, packed, coords, n, nullptr, act, act_bytes, 1, false, recomp)) return rc;
   const ActLayout a = act_layout(p, n, 1);
   const ScratchLayout sc = scratch_layout(p, n);

@@ -135,16 +135,18 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
 #pragma unroll
         for (int hr = 0; hr < 2; ++hr) {
           const int row = m_w + 16 * rb + 8 * hr + rr;
-          f32x4 lin, o;
+          f32x4 lin;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            lin[q] = a2[hr][q] + bv[q];
-            const float v = real_act_fwd_lean<ACT>(lin[q], ep.omega, ep.scale);
-            o[q] = col + q < ep.kvalid ? v : 0.f;                  // pad features are written as 0
-          }
-          if (row < M) {
-            if (ep.o0) *reinterpret_cast<f32x4*>(ep.o0 + (size_t)row * ep.ld0 + col) = lin;
-            *reinterpret_cast<f32x4*>(ep.o1 + (size_t)row * ep.ld1 + col) = o;
+          for (int q = 0; q < 4; ++q) lin[q] = a2[hr][q] + bv[q];
+          if (ep.o0 && row < M) *reinterpret_cast<f32x4*>(ep.o0 + (size_t)row * ep.ld0 + col) = lin;
+          if (ep.o1) {                                             // null: last hidden layer of a fused training step
+            f32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float v = real_act_fwd_lean<ACT>(lin[q], ep.omega, ep.scale);
+              o[q] = col + q < ep.kvalid ? v : 0.f;                // pad features are written as 0
+            }
+            if (row < M) *reinterpret_cast<f32x4*>(ep.o1 + (size_t)row * ep.ld1 + col) = o;
           }
         }
       }
@@ -168,9 +170,19 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
             // siren needs lin, relu needs out (its lin is never stored), gauss both
             lv[2 * r2 + hr] = (ACT != ACT_RELU) ? *reinterpret_cast<const f32x4*>(ep.i0 + (size_t)row * ep.ld0 + col)
                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
-            ov[2 * r2 + hr] = (ACT != ACT_SIREN) ? *reinterpret_cast<const f32x4*>(ep.i1 + (size_t)row * ep.ld1 + col)
-                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool load_out = ACT == ACT_RELU || (ACT == ACT_GAUSS && !ep.recompute_out);
+            ov[2 * r2 + hr] = load_out ? *reinterpret_cast<const f32x4*>(ep.i1 + (size_t)row * ep.ld1 + col)
+                                       : f32x4{0.f, 0.f, 0.f, 0.f};
           }
+        }
+        if (ACT == ACT_GAUSS && ep.recompute_out) {                // out = exp(-(s0 lin)^2) again: the forward's lean form
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float v = real_act_fwd_lean<ACT>(lv[e][q], ep.omega, ep.scale);
+              ov[e][q] = col + q < ep.kvalid ? v : 0.f;
+            }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
     const int64_t* __restrict__ idx, long long first, float gscale, float omega, float scale,
     float* __restrict__ y, float* __restrict__ rec, float* __restrict__ g_lin, float* __restrict__ part_w,
     float* __restrict__ part_b, float* __restrict__ loss_partial) {
-  static_assert(!RECOMP || KIND == NK_WIRE || KIND == NK_WIRE2D, "recompute exists for the Gabor activations only");
+  static_assert(!RECOMP || KIND != NK_RELU, "relu keeps out and has no lin to recompute it from");
   static_assert(RPW == 1 || (RPW == 2 && NPASS == 1), "two rows per wave slot: one pass of at most 256 columns");
   constexpr int RL = 64 / RPW;                         // lanes of one row
   constexpr bool HAS_LIN = (KIND != NK_RELU);          // relu: lin is never stored (lin > 0 <=> out > 0)
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
                      const f32x4 (&ll)[NPASS][NL]) {
     const long long row = row_slot + sub;                // this lane's row; past the end: contributes nothing
     const bool rl = row < r1;
-    if (RECOMP) {
+    if (RECOMP && (KIND == NK_WIRE || KIND == NK_WIRE2D)) {
       const float w0l2e = omega * 1.44269502f, ns2l2e = -(scale * scale) * 1.44269502f;
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
@@ -539,6 +539,17 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
           zi[ps][j] = valid ? b_ : 0.f;
         }
       }
+    } else if (RECOMP) {                                           // siren / gauss: 8 real features per lane and pass
+      constexpr int ACT = (KIND - NK_SIREN) < 0 ? 0 : (KIND - NK_SIREN);
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a_ = real_act_fwd_lean<ACT>(ll[ps][0][j], omega, scale);
+          const float b_ = real_act_fwd_lean<ACT>(ll[ps][1][j], omega, scale);
+          zr[ps][j] = (live[ps] && col[ps] + j < kvalid) ? a_ : 0.f;
+          zi[ps][j] = (live[ps] && col[ps] + 32 + j < kvalid) ? b_ : 0.f;
+        }
     }
     float yo[OT];
 #pragma unroll
@@ -703,7 +714,7 @@ hipError_t launch_final_fused(hipStream_t s, int kind, const float* out, const f
                               float* loss_out) {
   if (n <= 0) return hipSuccess;
   if (!final_fused_supported(P, O)) return hipErrorInvalidValue;
-  if (!out && kind != NK_WIRE && kind != NK_WIRE2D) return hipErrorInvalidValue;
+  if (!out && kind == NK_RELU) return hipErrorInvalidValue;
   const int nblk = final_bwd_blocks(n);
   const float inv = (float)(1.0 / ((double)n * (double)O));
   const size_t shm = final_fused_shm(P, O);
@@ -725,8 +736,12 @@ hipError_t launch_final_fused(hipStream_t s, int kind, const float* out, const f
     case NK_WIRE2D:                                                                                          \
       if (out) { FF_LAUNCH_O(NP, RW, NK_WIRE2D, false); } else { FF_LAUNCH_O(NP, RW, NK_WIRE2D, true); }     \
       break;                                                                                                 \
-    case NK_SIREN: FF_LAUNCH_O(NP, RW, NK_SIREN, false); break;                                              \
-    case NK_GAUSS: FF_LAUNCH_O(NP, RW, NK_GAUSS, false); break;                                              \
+    case NK_SIREN:                                                                                           \
+      if (out) { FF_LAUNCH_O(NP, RW, NK_SIREN, false); } else { FF_LAUNCH_O(NP, RW, NK_SIREN, true); }       \
+      break;                                                                                                 \
+    case NK_GAUSS:                                                                                           \
+      if (out) { FF_LAUNCH_O(NP, RW, NK_GAUSS, false); } else { FF_LAUNCH_O(NP, RW, NK_GAUSS, true); }       \
+      break;                                                                                                 \
     case NK_RELU: FF_LAUNCH_O(NP, RW, NK_RELU, false); break;                                                \
     default: return hipErrorInvalidValue;                                                                    \
   }
