@@ -389,18 +389,26 @@ def test_fused_step_equals_autograd_path_every_kind(case):
         assert e <= 2e-5, f"{case} grad {name}: {e:.2e}"
 
 
-def test_first_layer_sums_in_epilogue_agree_with_separate_pass():
-    """Knob "first_sums" (default 1): the first layer's weight / bias gradient g_u^T [x | 1] (autograd of
-    modules/wire.py:89 with is_first) is summed per 256-row tile inside the last data-gradient epilogue instead of a
-    separate pass over a stored g_u.  Another summation order, so agreement is to fp32 round-off; ragged row count."""
+@pytest.mark.parametrize("nonlin", ["wire", "siren", "gauss", "relu"])
+def test_first_layer_sums_in_epilogue_agree_with_separate_pass(nonlin):
+    """Knob "first_sums" (default 1): the first layer's weight / bias gradient g_0^T [x | 1] (autograd of
+    modules/wire.py:89 with is_first; siren.py:48-49, gauss.py:27-28, relu.py:28-29) is summed per 256-row tile inside
+    the last data-gradient epilogue instead of a separate pass over a stored g_0.  Another summation order, so
+    agreement is to fp32 round-off; ragged row count."""
     from wire_amd import _lib
+    from wire_amd.modules import models
     from wire_amd.trainer import FusedTrainer
     L = _lib.lib()
     res = []
     for knob in (0, 1):
         _lib.check(L.wire_tune_set(b"first_sums", knob))
         try:
-            model = _wire_model(2, 20.0, 30.0, hf=363, D=2, O=3, seed=4)
+            if nonlin == "wire":
+                model = _wire_model(2, 20.0, 30.0, hf=363, D=2, O=3, seed=4)
+            else:
+                torch.manual_seed(4)
+                model = models.get_INR(nonlin=nonlin, in_features=2, out_features=3, hidden_features=256,
+                                       hidden_layers=2, first_omega_0=30.0, hidden_omega_0=30.0, scale=10.0).to(DEV)
             g = torch.Generator().manual_seed(6)
             N = 67 * 71
             target = torch.rand(N, 3, generator=g)
@@ -410,7 +418,8 @@ def test_first_layer_sums_in_epilogue_agree_with_separate_pass():
             res.append(tr.flat_grad.clone())
         finally:
             _lib.check(L.wire_tune_set(b"first_sums", 1))
-    n0 = 256 * 2 * 2 + 256 * 2                        # first layer: complex W [256, 2] and b [256] as real pairs
+    # first layer: W [256, 2] and b [256] (complex for wire: real pairs)
+    n0 = (256 * 2 * 2 + 256 * 2) if nonlin == "wire" else (256 * 2 + 256)
     a, b = res[0].cpu().numpy(), res[1].cpu().numpy()
     assert np.abs(a[:n0]).max() > 0
     assert relmax(b[:n0], a[:n0]) <= 5e-6

@@ -486,6 +486,9 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
   float* gnext = Sx + sc.gb;
   const bool first_sums = g_first_sums && p.kind == WIRE_KIND_WIRE && p.x3 && p.L >= 1 &&
                           gemmx3_nt_is_h16(EPI_GABOR_BWD_FIRST, n);
+  // the same for siren / gauss / relu with a native first layer: the epilogue of the layer-1 data gradient sums g_lin_0 [x | 1]
+  const bool first_sums_real = g_first_sums && !p.cplx && !p.first_gemm && p.x3 && p.L >= 1 &&
+                               gemmx3_nt_is_h16(epi_bwd(p.kind), n);
 
   // ---- final linear + activation gradient of layer L
   const int nbf = final_bwd_blocks(n);
@@ -558,6 +561,7 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
       // hidden Gabor layer whose forward ran the lean 16 x 16 x 32 epilogue: out = act(lin) again, 8 B / element less
       // (real nets: only below a hidden layer -- the first layer's out comes from first_fwd_kernel's precise form)
       ep.recompute_out = g_recompute_out && p.x3 && (p.cplx || l - 1 >= 1) && gemmx3_nt_is_h16(epi_fwd(p.kind), n);
+      if (l == 1 && first_sums_real) { ep.coords = coords; ep.D = p.D; ep.cr_partial = Sx + sc.crp; ep.cr_C = p.K; }
     } else {
       epi = (p.kind == WIRE_KIND_WIRE) ? EPI_GABOR_BWD_FIRST : EPI_GABOR2D_BWD_FIRST;
       ep.omega = p.w1;
@@ -596,6 +600,8 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
       HIPCHK(launch_colreduce(s, gu + p.ldu, 2 * p.ldu, p.K, coords, p.D, n, Sx + sc.crp,
                               (float*)grads[2], (float*)grads[3]));
     }
+  } else if (!p.first_gemm && first_sums_real) {
+    HIPCHK(launch_colreduce_final(s, p.K, p.D, n, Sx + sc.crp, (float*)grads[0], (float*)grads[1]));
   } else if (!p.first_gemm) {
     // gcur holds g_lin_0 [n][P]
     const float* g0 = (p.L == 0) ? Sx + sc.ga : gcur;

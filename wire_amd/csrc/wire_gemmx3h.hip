@@ -157,6 +157,11 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
     for (int sp = 0; sp < 4; ++sp) {
       if (n_w + 32 * sp >= Nc) continue;
       const int col = n_w + 32 * sp + cq;
+      float crs[4][5];                                            // cr_partial: sums of g_lin_0 [x | 1] over this lane's rows
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int d = 0; d < 5; ++d) crs[q][d] = 0.f;
 #pragma unroll
       for (int rp = 0; rp < 4; rp += 2) {
         f32x4 lv[4], ov[4], a2[4];
@@ -190,8 +195,43 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
           f32x4 gl;
 #pragma unroll
           for (int q = 0; q < 4; ++q) gl[q] = real_act_bwd_lean<ACT>(a2[e][q], lv[e][q], ov[e][q], ep.omega, ep.scale);
-          if (row < M) *reinterpret_cast<f32x4*>(ep.o0 + (size_t)row * ep.ld0 + col) = gl;
+          if (row < M) {
+            if (ep.cr_partial) {
+              // first layer of a real net: its weight / bias gradient sums g_lin_0 [x | 1] are formed here (what
+              // colreduce_kernel would form from the stored g_lin_0 -- which is then never written)
+              float x[4] = {0.f, 0.f, 0.f, 0.f};
+              for (int d = 0; d < ep.D; ++d) x[d] = ep.coords[(size_t)row * ep.D + d];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) crs[q][d] = __builtin_fmaf(gl[q], x[d], crs[q][d]);
+                crs[q][4] += gl[q];
+              }
+            } else {
+              *reinterpret_cast<f32x4*>(ep.o0 + (size_t)row * ep.ld0 + col) = gl;
+            }
+          }
         }
+      }
+      if (ep.cr_partial) {                                         // 8 row lanes by shuffles; the 4 waves through LDS below
+        float* red = reinterpret_cast<float*>(lds);                // [4 waves][128 columns][5]
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int d = 0; d < 5; ++d) {
+            float v = crs[q][d];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+            if (rr == 0) red[(wave * 128 + 32 * sp + cq + q) * 5 + d] = v;
+          }
+      }
+    }
+    if (ep.cr_partial) {
+      __syncthreads();
+      const float* red = reinterpret_cast<const float*>(lds);
+      for (int e = threadIdx.x; e < 128 * 5; e += 256) {
+        const int c = e / 5, d = e - 5 * c;
+        const float v = (red[e] + red[128 * 5 + e]) + (red[2 * 128 * 5 + e] + red[3 * 128 * 5 + e]);
+        if (n_w + c < ep.cr_C) ep.cr_partial[((size_t)rt * ep.cr_C + n_w + c) * 5 + d] = v;
       }
     }
   } else if constexpr (EPI == EPI_GABOR2D_FWD) {
