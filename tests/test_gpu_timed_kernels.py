@@ -389,7 +389,7 @@ def test_fused_step_equals_autograd_path_every_kind(case):
         assert e <= 2e-5, f"{case} grad {name}: {e:.2e}"
 
 
-@pytest.mark.parametrize("nonlin", ["wire", "siren", "gauss", "relu"])
+@pytest.mark.parametrize("nonlin", ["wire", "wire2d", "siren", "gauss", "relu"])
 def test_first_layer_sums_in_epilogue_agree_with_separate_pass(nonlin):
     """Knob "first_sums" (default 1): the first layer's weight / bias gradient g_0^T [x | 1] (autograd of
     modules/wire.py:89 with is_first; siren.py:48-49, gauss.py:27-28, relu.py:28-29) is summed per 256-row tile inside
@@ -418,8 +418,11 @@ def test_first_layer_sums_in_epilogue_agree_with_separate_pass(nonlin):
             res.append(tr.flat_grad.clone())
         finally:
             _lib.check(L.wire_tune_set(b"first_sums", 1))
-    # first layer: W [256, 2] and b [256] (complex for wire: real pairs)
-    n0 = (256 * 2 * 2 + 256 * 2) if nonlin == "wire" else (256 * 2 + 256)
+    # the first layer's tensors (complex ones count as real pairs; wire2d: linear and scale_orth)
+    first = [v for k, v in model.state_dict().items() if k.startswith("net.0.") and "omega" not in k and "scale_0" not in k]
+    n0 = sum(v.numel() * (2 if v.is_complex() else 1) for v in first)
+    assert tr.offsets[len(first)] >= n0
+    n0 = tr.offsets[len(first)]                        # (tensors are 16-byte aligned in the flat buffer)
     a, b = res[0].cpu().numpy(), res[1].cpu().numpy()
     assert np.abs(a[:n0]).max() > 0
     assert relmax(b[:n0], a[:n0]) <= 5e-6

@@ -275,7 +275,8 @@ ScratchLayout scratch_layout(const Plan& p, int64_t n) {
   const int nbf = final_bwd_blocks(n) + 32;            // + pre-reduction scratch
   s.fpw = off; off += (int64_t)nbf * p.O * p.P;
   s.fpb = off; off += (int64_t)nbf * p.O + 64;
-  s.crp = off; off += (int64_t)(colreduce_blocks(n) + 32) * (p.cplx ? p.ldu : p.P) * 5;
+  // (wire2d: two sets, one per Linear of the first layer, when the data-gradient epilogue forms the sums itself)
+  s.crp = off; off += (int64_t)(colreduce_blocks(n) + 32) * (p.cplx ? p.ldu : p.P) * 5 * (p.kind == WIRE_KIND_WIRE2D ? 2 : 1);
   s.total = off;
   return s;
 }
@@ -484,8 +485,9 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
   auto lin_l = [&](int l) { return l == 0 ? A + a.lin0 : A + a.lin1 + (int64_t)(l - 1) * n * p.Pl; };
   float* gcur = Sx + sc.ga;
   float* gnext = Sx + sc.gb;
-  const bool first_sums = g_first_sums && p.kind == WIRE_KIND_WIRE && p.x3 && p.L >= 1 &&
-                          gemmx3_nt_is_h16(EPI_GABOR_BWD_FIRST, n);
+  const bool first_sums = g_first_sums && p.cplx && p.x3 && p.L >= 1 &&
+                          gemmx3_nt_is_h16(p.kind == WIRE_KIND_WIRE ? EPI_GABOR_BWD_FIRST : EPI_GABOR2D_BWD_FIRST, n);
+  const int64_t crp_set = (int64_t)(colreduce_blocks(n) + 32) * p.ldu * 5;   // wire2d: second set of partial sums
   // the same for siren / gauss / relu with a native first layer: the epilogue of the layer-1 data gradient sums g_lin_0 [x | 1]
   const bool first_sums_real = g_first_sums && !p.cplx && !p.first_gemm && p.x3 && p.L >= 1 &&
                                gemmx3_nt_is_h16(epi_bwd(p.kind), n);
@@ -568,7 +570,7 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
       ep.coords = coords; ep.D = p.D; ep.ldu = p.ldu; ep.o0 = Sx + sc.gu;
       // wire on the 16 x 16 x 32 kernel: its epilogue sums g_u [x | 1] per 256-row tile itself (the first layer's weight
       // and bias gradient partials) instead of storing g_u for a separate pass
-      if (first_sums) { ep.cr_partial = Sx + sc.crp; ep.cr_C = p.K; }
+      if (first_sums) { ep.cr_partial = Sx + sc.crp; ep.cr_C = p.K; ep.cr_set = crp_set; }
       // (and re-evaluates out_0 from the u it recomputes anyway: first_fwd_kernel's own form, the same bits)
       ep.recompute_out = g_recompute_out && p.x3 && p.kind == WIRE_KIND_WIRE && gemmx3_nt_is_h16(EPI_GABOR_BWD_FIRST, n);
       ep.W0 = packed + first_native_off(p, 0); ep.b0 = packed + first_native_off(p, 1);
@@ -594,6 +596,9 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
     } else if (p.kind == WIRE_KIND_WIRE) {
       HIPCHK(launch_colreduce(s, gu, p.ldu, p.K, coords, p.D, n, Sx + sc.crp, (float*)grads[0],
                               (float*)grads[1]));
+    } else if (first_sums) {
+      HIPCHK(launch_colreduce_final(s, p.K, p.D, n, Sx + sc.crp, (float*)grads[0], (float*)grads[1]));
+      HIPCHK(launch_colreduce_final(s, p.K, p.D, n, Sx + sc.crp + crp_set, (float*)grads[2], (float*)grads[3]));
     } else {
       HIPCHK(launch_colreduce(s, gu, 2 * p.ldu, p.K, coords, p.D, n, Sx + sc.crp, (float*)grads[0],
                               (float*)grads[1]));

@@ -37,6 +37,7 @@ struct GemmEpiParams {
   int wide = 0;                  // set by the launcher when 32-bit byte offsets could overflow
   float* cr_partial = nullptr;   // EPI_GABOR_BWD_FIRST of wire_gemmx3h.hip: per-256-row-tile sums [tile][cr_C][5] of
   int cr_C = 0;                  //   g_u [x | 1] (the first layer's weight / bias gradient) instead of storing g_u
+  int64_t cr_set = 0;            //   wire2d: floats between the sums of the layer's two Linears (g_u, g_p)
   int recompute_out = 0;         // EPI_GABOR_BWD of wire_gemmx3h.hip: out = act(lin) again instead of reading i1
   int stagger = 0, stagger_lo = 0, stagger_hi = 0;   // wire_gemmx3g.hip: late start (100 MHz ticks) of blocks [lo, hi)
 #ifdef WIRE_ABLATE

@@ -294,6 +294,11 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
       const int f0 = (grp << 5) + (c0 & 31);
       const int lc = (grp << 7) + (c0 & 31);                      // lin_re column in the 2P row
       float w[4][4], wv[4][4], bb[4], bv2[4];
+      float cru[4][5], crp2[4][5];                                // BWD_FIRST with cr_partial: sums of g_u [x | 1], g_p [x | 1]
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int d = 0; d < 5; ++d) { cru[q][d] = 0.f; crp2[q][d] = 0.f; }
       if constexpr (EPI == EPI_GABOR2D_BWD_FIRST) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -313,6 +318,7 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
         h_pair_rows(acc[rb][4 * G], acc[rb][4 * G + 1], are[0], are[1]);
         h_pair_rows(acc[rb][4 * G + 2], acc[rb][4 * G + 3], aim[0], aim[1]);
         f32x4 u[2], v[2], pp[2], qq[2], pr[2], pi[2];
+        float xs[2][4];                                           // BWD_FIRST: the rows' coordinates
 #pragma unroll
         for (int hr = 0; hr < 2; ++hr) {
           int row = m_w + 16 * rb + 8 * hr + rr;
@@ -342,6 +348,8 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
           } else {
             float x[4] = {0.f, 0.f, 0.f, 0.f};
             for (int d = 0; d < ep.D; ++d) x[d] = ep.coords[(size_t)row * ep.D + d];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) xs[hr][d] = x[d];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               float uu = bb[q], p2 = bv2[q];
@@ -377,11 +385,57 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
 #pragma unroll
               for (int q = 0; q < 4; ++q)
                 if (!(f0 + q < ep.kvalid)) { g0[q] = 0.f; g2[q] = 0.f; }
-              float* Gp = ep.o0 + (size_t)row * (2 * ep.ldu);
-              *reinterpret_cast<f32x4*>(Gp + f0) = g0;
-              *reinterpret_cast<f32x4*>(Gp + ep.ldu + f0) = g2;
+              if (ep.cr_partial) {
+                // first-layer gradient sums (both Linears of the layer) instead of a stored g_(u | p) and two passes
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                  for (int d = 0; d < 4; ++d) {
+                    cru[q][d] = __builtin_fmaf(g0[q], xs[hr][d], cru[q][d]);
+                    crp2[q][d] = __builtin_fmaf(g2[q], xs[hr][d], crp2[q][d]);
+                  }
+                  cru[q][4] += g0[q];
+                  crp2[q][4] += g2[q];
+                }
+              } else {
+                float* Gp = ep.o0 + (size_t)row * (2 * ep.ldu);
+                *reinterpret_cast<f32x4*>(Gp + f0) = g0;
+                *reinterpret_cast<f32x4*>(Gp + ep.ldu + f0) = g2;
+              }
             }
           }
+        }
+      }
+      if constexpr (EPI == EPI_GABOR2D_BWD_FIRST) {
+        if (ep.cr_partial) {                                       // 8 row lanes by shuffles; the 4 waves through LDS below
+          float* red = reinterpret_cast<float*>(lds);              // [2 sets][4 waves][64 features][5]
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int d = 0; d < 5; ++d) {
+              float a = cru[q][d], b = crp2[q][d];
+              a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4);
+              b += __shfl_xor(b, 1); b += __shfl_xor(b, 2); b += __shfl_xor(b, 4);
+              if (rr == 0) {
+                red[(wave * 64 + 32 * G + cq + q) * 5 + d] = a;
+                red[4 * 64 * 5 + (wave * 64 + 32 * G + cq + q) * 5 + d] = b;
+              }
+            }
+        }
+      }
+    }
+    if constexpr (EPI == EPI_GABOR2D_BWD_FIRST) {
+      if (ep.cr_partial) {
+        __syncthreads();
+        const float* red = reinterpret_cast<const float*>(lds);
+        const int fbase = (n_w >> 6) << 5;                          // first feature of this 128-column tile
+        for (int e = threadIdx.x; e < 2 * 64 * 5; e += 256) {
+          const int set = e / (64 * 5), r = e - set * (64 * 5);
+          const int f = r / 5, d = r - 5 * f;
+          const float* rs = red + set * (4 * 64 * 5);
+          const float v = (rs[r] + rs[64 * 5 + r]) + (rs[2 * 64 * 5 + r] + rs[3 * 64 * 5 + r]);
+          if (fbase + f < ep.cr_C)
+            ep.cr_partial[(size_t)set * ep.cr_set + ((size_t)rt * ep.cr_C + fbase + f) * 5 + d] = v;
         }
       }
     }
