@@ -406,14 +406,15 @@ hipError_t launch_final_bwd(hipStream_t s, int kind, int raw, const float* g_y, 
 // ---------------------------------------------------------------------------
 #define FF_MAXO 4
 #define FF_MAXPASS 2      // P <= 1024 floats per row
+#define FF_MAXROWS 512    // rows of one block (FB_ROWS <= rows <= FF_MAXROWS, chosen by the launcher)
 __global__ void mse_final_kernel(const float* __restrict__ partial, int nb, float lscale,
                                  float* __restrict__ loss_out);
 // (the kernel keeps 4 O P floats of W_f / partial sums in dynamic LDS: it must fit the 64 KB a launch gets
 // without an opt-in -- O = 4 with P = 1024 does not, and runs the unfused sequence instead)
 // dynamic LDS of the fused final stage: [4 waves][O][P] g_wf partials, [4][FF_MAXO + 1] bias / loss partials, then the
-// block's gathered targets [FB_ROWS][FF_MAXO] and source indices [FB_ROWS] (int64)
+// block's gathered targets [FF_MAXROWS][FF_MAXO] and source indices [FF_MAXROWS] (int64)
 static size_t final_fused_shm(int P, int O) {
-  return ((size_t)4 * O * P + 4 * (FF_MAXO + 1) + (size_t)FB_ROWS * FF_MAXO) * sizeof(float) + (size_t)FB_ROWS * 8;
+  return ((size_t)4 * O * P + 4 * (FF_MAXO + 1) + (size_t)FF_MAXROWS * FF_MAXO) * sizeof(float) + (size_t)FF_MAXROWS * 8;
 }
 bool final_fused_supported(int P, int O) {
   return (P % 64) == 0 && P <= 512 * FF_MAXPASS && O <= FF_MAXO && final_fused_shm(P, O) <= 65536;
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
     const float* __restrict__ wf, const float* __restrict__ bfr, const float* __restrict__ target,
     const int64_t* __restrict__ idx, long long first, float gscale, float omega, float scale,
     float* __restrict__ y, float* __restrict__ rec, float* __restrict__ g_lin, float* __restrict__ part_w,
-    float* __restrict__ part_b, float* __restrict__ loss_partial) {
+    float* __restrict__ part_b, float* __restrict__ loss_partial, int rows_pb) {
   static_assert(!RECOMP || KIND != NK_RELU, "relu keeps out and has no lin to recompute it from");
   static_assert(RPW == 1 || (RPW == 2 && NPASS == 1), "two rows per wave slot: one pass of at most 256 columns");
   constexpr int RL = 64 / RPW;                         // lanes of one row
@@ -444,8 +445,8 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
   const int sub = lane / RL, lr_ = lane & (RL - 1);    // row of the slot, lane inside the row
   const int ngrp = P >> 6;
   const int Pl = (KIND == NK_WIRE2D) ? 2 * P : P;      // row stride of lin / g_lin
-  const long long r0 = (long long)blockIdx.x * FB_ROWS;
-  long long r1 = r0 + FB_ROWS;
+  const long long r0 = (long long)blockIdx.x * rows_pb;
+  long long r1 = r0 + rows_pb;
   if (r1 > n) r1 = n;
   const float m2s2 = -2.f * scale * scale;
 
@@ -477,16 +478,16 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
 
   // the block's source indices and targets, gathered once by all 256 threads: inside the row loop the chain
   // idx[row] -> target[src] would be two dependent global loads per row and wave (it bounded the pass)
-  float* s_tg = sm + (size_t)4 * O * P + 4 * (FF_MAXO + 1);                       // [FB_ROWS][FF_MAXO]
-  long long* s_src = reinterpret_cast<long long*>(s_tg + FB_ROWS * FF_MAXO);      // [FB_ROWS]
-  {
-    const long long grow = r0 + threadIdx.x;
+  float* s_tg = sm + (size_t)4 * O * P + 4 * (FF_MAXO + 1);                       // [FF_MAXROWS][FF_MAXO]
+  long long* s_src = reinterpret_cast<long long*>(s_tg + FF_MAXROWS * FF_MAXO);   // [FF_MAXROWS]
+  for (int t = threadIdx.x; t < rows_pb; t += 256) {
+    const long long grow = r0 + t;
     if (grow < r1) {
       const long long src = idx ? idx[grow] : first + grow;
-      s_src[threadIdx.x] = src;
+      s_src[t] = src;
 #pragma unroll
       for (int o = 0; o < OT; ++o)
-        if (o < O) s_tg[threadIdx.x * FF_MAXO + o] = target[src * O + o];
+        if (o < O) s_tg[t * FF_MAXO + o] = target[src * O + o];
     }
   }
   __syncthreads();
@@ -715,13 +716,29 @@ hipError_t launch_final_fused(hipStream_t s, int kind, const float* out, const f
   if (n <= 0) return hipSuccess;
   if (!final_fused_supported(P, O)) return hipErrorInvalidValue;
   if (!out && kind == NK_RELU) return hipErrorInvalidValue;
-  const int nblk = final_bwd_blocks(n);
+  // Rows per block: the kernel runs 3 blocks per CU (registers), i.e. 768 at a time; 1024 blocks of FB_ROWS rows at
+  // n = 262 144 would be one full round and a second one on a third of the chip.  So a block takes as many rows as
+  // it needs for ONE round (342 -> 767 blocks), within the FB_ROWS-block partial-sum layout of launch_final_reduce:
+  // fewer blocks than final_bwd_blocks(n), the unused partial slots are zeroed.
+  const int nbf = final_bwd_blocks(n);
+  int rows_pb = FB_ROWS;
+  if (nbf > 768) {
+    rows_pb = (int)((n + 767) / 768);
+    rows_pb = (rows_pb + 7) & ~7;
+    if (rows_pb > FF_MAXROWS) rows_pb = FF_MAXROWS;
+  }
+  const int nblk = (int)((n + rows_pb - 1) / rows_pb);
+  if (nblk < nbf) {
+    hipError_t e = hipMemsetAsync(part_w + (size_t)nblk * O * P, 0, (size_t)(nbf - nblk) * O * P * sizeof(float), s);
+    if (e == hipSuccess) e = hipMemsetAsync(part_b + (size_t)nblk * O, 0, (size_t)(nbf - nblk) * O * sizeof(float), s);
+    if (e != hipSuccess) return e;
+  }
   const float inv = (float)(1.0 / ((double)n * (double)O));
   const size_t shm = final_fused_shm(P, O);
 #define FF_LAUNCH(NP, RW, KD, RC, OT)                                                                        \
   hipLaunchKernelGGL((final_fused_kernel<NP, KD, RC, OT, RW>), dim3((unsigned)nblk), dim3(256), shm, s, out, \
                      lin, (long long)n, P, O, kvalid, wf, bfr, target, idx, (long long)first,                \
-                     weight * 2.f * inv, omega, scale, y, rec, g_lin, part_w, part_b, loss_partial)
+                     weight * 2.f * inv, omega, scale, y, rec, g_lin, part_w, part_b, loss_partial, rows_pb)
 #define FF_LAUNCH_O(NP, RW, KD, RC)                                                                          \
   switch (O) {                                                                                               \
     case 1: FF_LAUNCH(NP, RW, KD, RC, 1); break;                                                             \
