@@ -144,25 +144,75 @@ def family_ctx(fam):
     return ctx()
 
 
-def wire_oracle_grads_chunked(P, coords, target, L, om1, om, sc, double, chunk=16384):
+def _host_threads():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def oracle_grads_chunked(kind, P, coords, target, L, om1, om, sc, double, nf=None, chunk=16384):
     """Loss and every parameter gradient of the MSE over ALL rows (mean over n x O elements,
-    wire_image_denoise.py:153), evaluated by the numpy oracle in row chunks so that BASELINE.json's full batch
-    (262 144 x 256 complex128 activations = 0.5 GB per layer) stays small.  Gradients are summed in the chunk's
-    own precision.  Returns (y, loss, grads)."""
+    wire_image_denoise.py:153), evaluated by the numpy oracle in row chunks so that BASELINE.json's full batches
+    (262 144 x 256 complex128 activations = 0.5 GB per layer; 1 048 576 rows for wire2d) stay small; the chunks run on
+    a thread pool (numpy releases the GIL; one BLAS thread per worker) and are summed in chunk order, in the chunk's
+    own precision.  kind: 'wire' (modules/wire.py:161-167), 'wire2d' (modules/wire2d.py:56-67,124-130), 'siren' /
+    'gauss' / 'relu' (modules/siren.py:90-96, gauss.py:71-74, relu.py:124-130; ``nf`` = number of positional-encoding
+    frequencies, relu.py:62-75, or None).  Returns (y, loss, grads)."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import wire_oracle as wo
     rdt = np.float64 if double else np.float32
     p = wo.cast_params(P, double)
     n, O = target.shape[0], target.shape[1]
-    ys, grads, sq = [], None, 0.0
-    for s in range(0, n, chunk):
+
+    def one(s):
         c = coords[s:s + chunk].astype(rdt)
         t = target[s:s + chunk].astype(rdt)
-        y, cache = wo.wire_forward(p, c, L, rdt(om1), rdt(om), rdt(sc), keep=True)
+        a = (rdt(om1), rdt(om), rdt(sc))
+        if kind == "wire":
+            y, cache = wo.wire_forward(p, c, L, *a, keep=True)
+        elif kind == "wire2d":
+            y, cache = wo.wire2d_forward(p, c, L, *a, keep=True)
+        else:
+            y, cache = wo.realnet_forward(kind, p, c, L, *a, nf, keep=True)
         diff = y - t
-        sq += float(np.square(diff.astype(np.float64)).sum())
+        sq = float(np.square(diff.astype(np.float64)).sum())
         gy = (rdt(2.0) / rdt(n * O)) * diff
-        g = wo.wire_backward(p, cache, gy, L, rdt(om1), rdt(om), rdt(sc))
+        if kind == "wire":
+            g = wo.wire_backward(p, cache, gy, L, *a)
+        elif kind == "wire2d":
+            g = wo.wire2d_backward(p, cache, gy, L, *a)
+        else:
+            g = wo.realnet_backward(kind, p, cache, gy, L, *a)
+        return y, sq, g
+
+    starts = list(range(0, n, chunk))
+    workers = min(_host_threads(), len(starts))
+    if workers > 1:
+        try:
+            from threadpoolctl import threadpool_limits
+            limit = threadpool_limits(limits=1)
+        except Exception:
+            limit = None
+        try:
+            with ThreadPoolExecutor(max_workers=workers) as ex:
+                parts = list(ex.map(one, starts))
+        finally:
+            if limit is not None:
+                limit.restore_original_limits()
+    else:
+        parts = [one(s) for s in starts]
+    grads, sq = None, 0.0
+    for _, q, g in parts:
+        sq += q
         grads = g if grads is None else {k: grads[k] + g[k] for k in g}
-        ys.append(y)
-        del cache
-    return np.concatenate(ys, 0), sq / (n * O), grads
+    return np.concatenate([y for y, _, _ in parts], 0), sq / (n * O), grads
+
+
+def wire_oracle_grads_chunked(P, coords, target, L, om1, om, sc, double, chunk=16384):
+    """oracle_grads_chunked for the 1-D Gabor net (modules/wire.py:161-167)."""
+    return oracle_grads_chunked("wire", P, coords, target, L, om1, om, sc, double, None, chunk)

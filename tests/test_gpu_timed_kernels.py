@@ -22,8 +22,8 @@ import numpy as np
 import pytest
 import torch
 
-from _util import (family_ctx, final_bias_within_ref, params_np, relmax, wire_oracle_grads_chunked,
-                   within_ref)
+from _util import (family_ctx, final_bias_within_ref, oracle_grads_chunked, params_np, relmax,
+                   wire_oracle_grads_chunked, within_ref)
 from oracle import wire_oracle as wo
 
 pytestmark = pytest.mark.gpu
@@ -273,6 +273,79 @@ def test_fused_trainer_step_gradients_vs_fp64_oracle(case):
     assert abs(float(loss.item()) - l64) <= (2 * abs(l32 - l64) / l64 + 1e-5) * l64
     flat = tr.flat_grad.cpu().numpy()
     names = [k for k in model.state_dict().keys() if "omega_0" not in k and "scale_0" not in k]
+    for name, off in zip(names, tr.offsets):
+        ref = wo.as_real_pairs(g64[name]).astype(np.float64).ravel()
+        ref32 = wo.as_real_pairs(g32[name]).astype(np.float64).ravel()
+        mine = flat[off:off + ref.size]
+        if name == f"net.{Ln + 1}.bias":
+            final_bias_within_ref(mine, ref, err_y_ref, np.abs(y64).max(), On, f"{tag} grad {name}",
+                                  resid_max=np.abs(y64 - tgt).max())
+        else:
+            within_ref(relmax(mine, ref), relmax(ref32, ref), f"{tag} grad {name}")
+
+
+# ---------------------------------------------------------------------------
+# the timed step of BASELINE.json configs[3] / [4] and of the reference-API width, AT BENCH SIZE
+# ---------------------------------------------------------------------------
+KIND_STEP_CASES = {
+    # name: (get_INR kwargs, grid)   -- the very calls of bench.py's extras (timed_config)
+    "cfg4_wire2d_4x256_1024x1024": (dict(nonlin="wire2d", hidden_features=256, first_omega_0=10.0, hidden_omega_0=10.0,
+                                         scale=10.0), (1024, 1024)),
+    "cfg5_siren_4x256_512x512": (dict(nonlin="siren", hidden_features=256, first_omega_0=30.0, hidden_omega_0=30.0),
+                                 (512, 512)),
+    "cfg5_gauss_4x256_512x512": (dict(nonlin="gauss", hidden_features=256, scale=10.0), (512, 512)),
+    "cfg5_relu_4x256_512x512": (dict(nonlin="relu", hidden_features=256), (512, 512)),
+    "cfg5_relu_posenc_4x256_512x512": (dict(nonlin="relu", hidden_features=256, pos_encode=True, sidelength=512),
+                                       (512, 512)),
+    "k181_api_hidden_features_256_512x512": (dict(nonlin="wire", hidden_features=256, first_omega_0=20.0,
+                                                  hidden_omega_0=20.0, scale=30.0), (512, 512)),
+    "k212_occupancy_3x300_64x64x64": (dict(nonlin="wire", hidden_features=300, hidden_layers=3, in_features=3,
+                                           out_features=1, first_omega_0=20.0, hidden_omega_0=20.0, scale=10.0),
+                                      (64, 64, 64)),
+}
+
+
+@pytest.mark.parametrize("case", list(KIND_STEP_CASES))
+def test_fused_trainer_step_every_kind_vs_fp64_oracle_at_bench_size(case):
+    """the fused step bench.py times for BASELINE.json configs[3] (wire2d 4x256 on 1024^2 =
+    1 048 576 rows) and configs[4] (siren / gauss / relu / relu+posenc 4x256 on 512^2) and for the reference-API widths
+    (hidden_features=256 -> K = 181, P = 384; the 3x300 occupancy net -> K = 212, P = 448) -- gemmx3h_nt with the real /
+    2-D epilogues incl. the first-layer sums, the single-tile / ragged-width weight-gradient kernels, final_fused_kernel
+    with recompute_out -- against the numpy fp64 oracle on the same weights: output, loss and EVERY parameter gradient,
+    ``err_build <= 2 err_ref + 1e-6`` with err_ref = the same oracle in fp32.  Reference arithmetic:
+    modules/wire2d.py:56-67, siren.py:48-49, gauss.py:27-28, relu.py:28-29,62-75, wire.py:88-93."""
+    from wire_amd.modules import models
+    from wire_amd.trainer import FusedTrainer
+    kw, grid = KIND_STEP_CASES[case]
+    kw = dict(kw)
+    kind = kw["nonlin"]
+    Dn, On, Ln = kw.pop("in_features", 2), kw.pop("out_features", 3), kw.pop("hidden_layers", 4)
+    torch.manual_seed(0)
+    model = models.get_INR(in_features=Dn, out_features=On, hidden_layers=Ln, **kw).to(DEV)
+    N = int(np.prod(grid))
+    g = torch.Generator().manual_seed(11)
+    target = torch.rand(N, On, generator=g)
+    perm = torch.randperm(N, generator=g)
+    three_d = len(grid) == 3
+    tr = FusedTrainer(model, grid, target, lr=0.0, keep_rec=True, coords_style="numpy" if three_d else "torch")
+    loss = tr.step(perm.to(DEV))
+    torch.cuda.synchronize()
+    P = params_np(model)
+    coords = (wo.volume_coords(*grid) if three_d else wo.image_coords(*grid))[perm.numpy()]
+    tgt = target.numpy()[perm.numpy()]
+    om1 = kw.get("first_omega_0", 30.0)
+    om = kw.get("hidden_omega_0", 30.0)
+    sc = kw.get("scale", 10.0)
+    nf = wo.posenc_num_frequencies(Dn, kw["sidelength"]) if kw.get("pos_encode") else None
+    y64, l64, g64 = oracle_grads_chunked(kind, P, coords, tgt, Ln, om1, om, sc, True, nf)
+    y32, l32, g32 = oracle_grads_chunked(kind, P, coords, tgt, Ln, om1, om, sc, False, nf)
+    tag = f"step[{case}]"
+    err_y_ref = relmax(y32, y64)
+    within_ref(relmax(tr.rec.cpu().numpy()[perm.numpy()], y64), err_y_ref, tag + " y")
+    assert abs(float(loss.item()) - l64) <= (2 * abs(l32 - l64) / l64 + 1e-5) * l64
+    flat = tr.flat_grad.cpu().numpy()
+    names = [k for k in model.state_dict().keys() if "omega_0" not in k and "scale_0" not in k]
+    assert set(names) == set(g64.keys())
     for name, off in zip(names, tr.offsets):
         ref = wo.as_real_pairs(g64[name]).astype(np.float64).ravel()
         ref32 = wo.as_real_pairs(g32[name]).astype(np.float64).ravel()

@@ -131,3 +131,25 @@ def test_utils_match_reference_known_answers():
     from wire_amd.modules.relu import PosEncoding
     pe = PosEncoding(2, sidelength=512)
     np.testing.assert_allclose(pe(torch.tensor(misc["posenc2_in"])).numpy(), misc["posenc2_out"], atol=1e-6)
+
+
+def test_fused_trainer_rejects_layerwise_and_trainable_nets():
+    """FusedTrainer runs the descriptor's net (linear output, fixed omega_0 / scale_0).  A net that
+    HipINR.forward runs layer by layer -- outermost_linear=False (modules/siren.py:81-84, gauss.py:63-66,
+    relu.py:116-119) or trainable=True layers (modules/wire.py:80-81) -- is a different function there and must be
+    refused, not silently trained as something else."""
+    import pytest
+    import torch
+    from wire_amd.modules import models
+    from wire_amd.modules.wire import ComplexGaborLayer
+    from wire_amd.trainer import FusedTrainer
+    tgt = torch.zeros(16 * 16, 3)
+    m = models.get_INR(nonlin="siren", in_features=2, out_features=3, hidden_features=32, hidden_layers=1,
+                       outermost_linear=False)
+    with pytest.raises(NotImplementedError, match="outermost_linear"):
+        FusedTrainer(m, (16, 16), tgt)
+    m = models.get_INR(nonlin="wire", in_features=2, out_features=3, hidden_features=32, hidden_layers=1)
+    m.net[1] = ComplexGaborLayer(m.net[1].linear.in_features, m.net[1].linear.out_features, omega0=5.0, sigma0=5.0,
+                                 trainable=True)
+    with pytest.raises(NotImplementedError, match="trainable"):
+        FusedTrainer(m, (16, 16), tgt)

@@ -1,0 +1,8 @@
+#!/bin/bash
+# builds build/gemm_x2_tune (2 x fp16 split NT / TN GEMMs against the 3 x bf16 ones); run from the repo root
+set -e
+mkdir -p build
+make -C wire_amd/csrc -j8 >/dev/null
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -c tools/gemm_x2_tune.hip -o build/gemm_x2_tune.o
+hipcc --offload-arch=gfx950 build/gemm_x2_tune.o build/csrc/wire_gemm.o build/csrc/wire_gemm3m.o build/csrc/wire_gemmx3.o \
+      build/csrc/wire_gemmx3g.o build/csrc/wire_gemmx3h.o build/csrc/wire_gemmx2h.o -o build/gemm_x2_tune

@@ -17,6 +17,10 @@
 #include "wire_gemm.h"
 #include "wire_point.h"
 
+#ifndef WIRE_AMAX_SLOTS
+#define WIRE_AMAX_SLOTS 64            // wire_dev.h (device header): sharded max-|value| slots per operand tensor
+#endif
+
 // ---------------------------------------------------------------------------
 // error plumbing
 // ---------------------------------------------------------------------------
@@ -109,6 +113,10 @@ static int env_flag(const char* name, int dflt) {
 }
 // every net: split-bf16 GEMMs on the bf16 MFMA (wire_gemmx3.hip); overrides complex_3m
 static int g_split_bf16 = env_flag("WIRE_SPLIT_BF16", 1);
+// hidden-layer GEMMs of batches >= 4096 rows as a 2 x fp16 split on the f16 MFMA (wire_gemmx2h.hip): 3 instead of 6
+// matrix-core products per fp32 product, operand scales from device-side maxima; needs split_bf16 and the 16 x 16 x 32
+// kernels (x3_h16) for the net kind, falls back to the 3 x bf16 kernels otherwise
+static int g_split_f16 = env_flag("WIRE_SPLIT_F16", 1);
 // family the flags select for a net kind (wire_layer_api.hip): 2 split-bf16, 1 complex 3M (wire only), 0 4M
 int wire_family_(int kind) {
   if (g_split_bf16) return 2;
@@ -121,6 +129,7 @@ extern "C" int wire_tune_get(const char* key) {
   if (!strcmp(key, "x3_h16")) return gemmx3h_mode();
   if (!strcmp(key, "x3_tn16")) return gemmx3_tn16_mode();
   if (!strcmp(key, "recompute_out")) return g_recompute_out;
+  if (!strcmp(key, "split_f16")) return g_split_f16;
   return fail(WIRE_ERR_ARG, "unknown tuning key: %s", key);
 }
 extern "C" int wire_tune_set(const char* key, int value) {
@@ -129,6 +138,8 @@ extern "C" int wire_tune_set(const char* key, int value) {
   if (!strcmp(key, "split_bf16")) { g_split_bf16 = value ? 1 : 0; return WIRE_OK; }
   if (!strcmp(key, "recompute_out")) { g_recompute_out = value ? 1 : 0; return WIRE_OK; }
   if (!strcmp(key, "first_sums")) { g_first_sums = value ? 1 : 0; return WIRE_OK; }
+  if (!strcmp(key, "split_f16")) { g_split_f16 = value ? 1 : 0; return WIRE_OK; }
+  if (gemmx2h_tune_set(key, value) == 0) return WIRE_OK;
   if (gemm_tune_set(key, value) == 0) return WIRE_OK;
   if (gemmx3_tune_set(key, value) == 0) return WIRE_OK;
   return fail(WIRE_ERR_ARG, "unknown tuning key or bad value: %s=%d", key, value);
@@ -143,11 +154,11 @@ inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 struct Plan {
   int kind, D, K, L, O, F;
   float w1, w, s;
-  bool cplx, first_gemm, m3, x3;
+  bool cplx, first_gemm, m3, x3, x2;
   int P, Pl, Din, Pin0, ldu, ntens, per_layer, Kp;
   // packed image offsets (floats); index l = 0..L (l = 0 only when first_gemm)
-  std::vector<int64_t> off_fwd, off_dg, off_bias, off_fwd_x3, off_dg_x3, off_fwd_3m, off_dg_3m;
-  int64_t off_wf, off_bf, off_first, total_packed;
+  std::vector<int64_t> off_fwd, off_dg, off_bias, off_fwd_x3, off_dg_x3, off_fwd_3m, off_dg_3m, off_fwd_x2, off_dg_x2;
+  int64_t off_wf, off_bf, off_first, off_wamax, total_packed;   // off_wamax: max-|weight| slots, WIRE_AMAX_SLOTS per layer
   std::vector<int64_t> tfloats;
 };
 
@@ -168,6 +179,7 @@ int make_plan(const wire_net_desc* d, Plan& p) {
   p.ldu = p.P / 2;
   p.Kp = p.P / 2;
   p.x3 = g_split_bf16 != 0;
+  p.x2 = p.x3 && g_split_f16 != 0;
   p.m3 = (p.kind == WIRE_KIND_WIRE) && g_complex_3m && !p.x3;
   p.first_gemm = p.F > 0;
   p.Din = p.first_gemm ? p.D + 2 * p.D * p.F : p.D;
@@ -191,6 +203,7 @@ int make_plan(const wire_net_desc* d, Plan& p) {
   p.off_fwd.assign(p.L + 1, -1); p.off_dg.assign(p.L + 1, -1); p.off_bias.assign(p.L + 1, -1);
   p.off_fwd_x3.assign(p.L + 1, -1); p.off_dg_x3.assign(p.L + 1, -1);
   p.off_fwd_3m.assign(p.L + 1, -1); p.off_dg_3m.assign(p.L + 1, -1);
+  p.off_fwd_x2.assign(p.L + 1, -1); p.off_dg_x2.assign(p.L + 1, -1);
   for (int l = p.first_gemm ? 0 : 1; l <= p.L; ++l) {
     const int64_t pin = (l == 0) ? p.Pin0 : p.P;
     // every family's image is ALWAYS written by wire_pack_params (real-expanded fp32, its split-bf16 form and,
@@ -206,7 +219,12 @@ int make_plan(const wire_net_desc* d, Plan& p) {
       p.off_fwd_3m[l] = off; off += (int64_t)p.Kp * p.P;
       p.off_dg_3m[l] = off; off += (int64_t)p.Kp * p.P;
     }
+    if (l >= 1) {                                         // 2 x fp16 images of the hidden layers
+      p.off_fwd_x2[l] = off; off += gemmx2_b_image_floats(p.Pl, (int)pin);
+      p.off_dg_x2[l] = off; off += gemmx2_b_image_floats((int)pin, p.Pl);
+    }
   }
+  p.off_wamax = off; off += (int64_t)(p.L + 1) * WIRE_AMAX_SLOTS;
   p.off_wf = off; off += (int64_t)p.O * p.P;
   p.off_bf = off; off += 64;
   p.off_first = off;   // native copies of the first layer's tensors (W0,b0[,V0,c0])
@@ -225,10 +243,12 @@ inline int64_t first_native_off(const Plan& p, int q) {
 struct ActLayout {
   int64_t pe, out0, lin0, lin1, total;   // out_l = out0 + l*n*P ; lin_l = lin1 + (l-1)*n*Pl
   int64_t ping, pong;                    // inference
+  int64_t amax;                          // max |out_l| slots, WIRE_AMAX_SLOTS per layer l = 0..L (2 x fp16 GEMMs)
 };
 ActLayout act_layout(const Plan& p, int64_t n, int save) {
   ActLayout a{};
   int64_t off = 0;
+  a.amax = off; off += (int64_t)(p.L + 2) * WIRE_AMAX_SLOTS;
   a.pe = off; if (p.first_gemm) off += n * p.Pin0;
   if (save) {
     a.out0 = off; off += n * p.P * (p.L + 1);
@@ -242,10 +262,11 @@ ActLayout act_layout(const Plan& p, int64_t n, int save) {
   return a;
 }
 
-struct ScratchLayout { int64_t ga, gb, gu, slab, bslab, fpw, fpb, crp, total; int S; };
+struct ScratchLayout { int64_t ga, gb, gu, slab, bslab, fpw, fpb, crp, gamax, total; int S; };
 ScratchLayout scratch_layout(const Plan& p, int64_t n) {
   ScratchLayout s{};
   int64_t off = 0;
+  s.gamax = off; off += (int64_t)(p.L + 2) * WIRE_AMAX_SLOTS;   // max |g_lin_l| slots (2 x fp16 GEMMs)
   s.ga = off; off += n * p.Pl;
   s.gb = off; off += n * p.Pl;
   s.gu = off; if (p.cplx) off += n * p.ldu * (p.kind == WIRE_KIND_WIRE2D ? 2 : 1);
@@ -281,6 +302,13 @@ ScratchLayout scratch_layout(const Plan& p, int64_t n) {
   return s;
 }
 
+int epi_fwd(int kind);
+int epi_bwd(int kind);
+// the hidden-layer GEMMs of this call run as 2 x fp16 splits: every forward / data-gradient launch is then a 16 x 16 x 32
+// kernel (M >= 4096, x3_h16 bits of the kind), whose epilogues track the maxima the next GEMM scales by
+bool use_x2(const Plan& p, int64_t n) {
+  return p.x2 && p.L >= 1 && gemmx3_nt_is_h16(epi_fwd(p.kind), n) && gemmx3_nt_is_h16(epi_bwd(p.kind), n);
+}
 int epi_fwd(int kind) {
   switch (kind) {
     case WIRE_KIND_WIRE: return EPI_GABOR_FWD;
@@ -340,6 +368,7 @@ extern "C" int wire_pack_params(void* stream, const wire_net_desc* d, const void
   ProfScope ps(s, 3, 0);
   for (int i = 0; i < p.ntens; ++i)
     if (!params[i]) return fail(WIRE_ERR_ARG, "params[%d] is null", i);
+  HIPCHK(hipMemsetAsync(packed + p.off_wamax, 0, (size_t)(p.L + 1) * WIRE_AMAX_SLOTS * sizeof(float), s));
   if (p.first_gemm) {                                    // layer 0 as a GEMM (positional encoding): its own shape
     const float* W = (const float*)params[0];
     const float* b = (const float*)params[1];
@@ -378,6 +407,22 @@ extern "C" int wire_pack_params(void* stream, const wire_net_desc* d, const void
     }
     if (p.off_fwd_3m[l0] >= 0)    // same bias image (blocked planar) as the hidden pack wrote
       HIPCHK(launch_pack3m_batch(s, p3, nb, p.K, p.K, p.Kp, p.Kp));
+    {
+      // 2 x fp16 images: max |weight| of each layer (the forward and the transposed image hold the same values), then
+      // the scaled split of both images
+      X2AmaxBatch ab{};
+      X2SplitBatch xf{}, xd{};
+      for (int i = 0; i < nb; ++i) {
+        const int l = l0 + i;
+        unsigned* slots = reinterpret_cast<unsigned*>(packed + p.off_wamax + (int64_t)l * WIRE_AMAX_SLOTS);
+        ab.src[i] = packed + p.off_fwd[l]; ab.slots[i] = slots;
+        xf.src[i] = packed + p.off_fwd[l]; xf.dst[i] = packed + p.off_fwd_x2[l]; xf.slots[i] = slots;
+        xd.src[i] = packed + p.off_dg[l]; xd.dst[i] = packed + p.off_dg_x2[l]; xd.slots[i] = slots;
+      }
+      HIPCHK(launch_amax_batch(s, ab, nb, (int64_t)p.Pl * p.P));
+      HIPCHK(launch_x2_split_b_batch(s, xf, nb, p.P, p.Pl, p.P));
+      HIPCHK(launch_x2_split_b_batch(s, xd, nb, p.Pl, p.P, p.Pl));
+    }
   }
   HIPCHK(launch_pack_final(s, p.kind, (const float*)params[p.ntens - 2],
                            (const float*)params[p.ntens - 1], p.K, p.P, p.O, packed + p.off_wf,
@@ -403,6 +448,10 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
                                            (long long)act_bytes, (long long)a.total * 4);
   hipStream_t s = (hipStream_t)stream;
   float* A = (float*)act;
+  const bool x2 = use_x2(p, n);
+  unsigned* const amax = reinterpret_cast<unsigned*>(A + a.amax);            // slots of out_l at amax + 64 l
+  auto wamax = [&](int l) { return reinterpret_cast<const unsigned*>(packed + p.off_wamax + (int64_t)l * WIRE_AMAX_SLOTS); };
+  if (x2) HIPCHK(hipMemsetAsync(amax, 0, (size_t)(p.L + 2) * WIRE_AMAX_SLOTS * sizeof(unsigned), s));
   auto out_l = [&](int l) { return save_for_bwd ? A + a.out0 + (int64_t)l * n * p.P
                                                 : A + ((l & 1) ? a.pong : a.ping); };
   auto lin_l = [&](int l) -> float* {
@@ -416,6 +465,7 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
       HIPCHK(launch_posenc(s, coords, n, p.D, p.F, p.Pin0, A + a.pe)); }
     GemmEpiParams ep; ep.bias = packed + p.off_bias[0]; ep.o0 = lin_l(0); ep.o1 = out_l(0);
     ep.ld0 = p.Pl; ep.ld1 = p.P; ep.omega = p.w1; ep.scale = p.s; ep.kvalid = p.K;
+    if (x2) ep.amax_out = amax;                          // (the 3 x bf16 16 x 16 x 32 kernel tracks the maximum too)
     ProfScope ps(s, 0, 2.0 * n * p.Pl * p.Pin0);
     if (p.x3)
       HIPCHK(launch_gemmx3_nt(s, epi_fwd(p.kind), A + a.pe, p.Pin0, packed + p.off_fwd_x3[0], n, p.Pl,
@@ -430,7 +480,7 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
     const float* c0 = p.per_layer == 4 ? packed + first_native_off(p, 3) : nullptr;
     ProfScope ps(s, 3, 0);
     HIPCHK(launch_first_fwd(s, p.kind, coords, n, p.D, W0, b0, V0, c0, p.K, p.P, p.w1, p.s,
-                            p.cplx ? nullptr : lin_l(0), out_l(0)));
+                            p.cplx ? nullptr : lin_l(0), out_l(0), x2 ? amax : nullptr));
   }
   // ---- hidden layers
   for (int l = 1; l <= p.L; ++l) {
@@ -438,7 +488,10 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
     ep.ld0 = p.Pl; ep.ld1 = p.P; ep.omega = p.w; ep.scale = p.s; ep.kvalid = p.K;
     if (skip_last_out && l == p.L) ep.o1 = nullptr;       // wire_train_fwd_bwd: the final stage recomputes it
     ProfScope ps(s, 0, 2.0 * n * p.Pl * p.P);
-    if (p.m3)
+    if (x2) {
+      ep.amax_a = amax + (l - 1) * WIRE_AMAX_SLOTS; ep.amax_b = wamax(l); ep.amax_out = amax + l * WIRE_AMAX_SLOTS;
+      HIPCHK(launch_gemmx2h_nt(s, epi_fwd(p.kind), out_l(l - 1), p.P, packed + p.off_fwd_x2[l], n, p.Pl, p.P, ep));
+    } else if (p.m3)
       HIPCHK(launch_gemm3m_nt(s, EPI_GABOR_FWD, out_l(l - 1), p.P, packed + p.off_fwd_3m[l], p.P, n, p.Kp,
                               p.Kp, ep));
     else if (p.x3)
@@ -485,6 +538,12 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
   auto lin_l = [&](int l) { return l == 0 ? A + a.lin0 : A + a.lin1 + (int64_t)(l - 1) * n * p.Pl; };
   float* gcur = Sx + sc.ga;
   float* gnext = Sx + sc.gb;
+  const bool x2 = use_x2(p, n);
+  unsigned* const gamax = reinterpret_cast<unsigned*>(Sx + sc.gamax);          // slots of g_lin_l at gamax + 64 l
+  const unsigned* const amax = reinterpret_cast<const unsigned*>(A + a.amax);  // slots of out_l, filled by the forward
+  auto wamax = [&](int l) { return reinterpret_cast<const unsigned*>(packed + p.off_wamax + (int64_t)l * WIRE_AMAX_SLOTS); };
+  // (the fused path zeroed the slots before its final stage published max |g_lin_L|)
+  if (x2 && do_final) HIPCHK(hipMemsetAsync(gamax, 0, (size_t)(p.L + 2) * WIRE_AMAX_SLOTS * sizeof(unsigned), s));
   const bool first_sums = g_first_sums && p.cplx && p.x3 && p.L >= 1 &&
                           gemmx3_nt_is_h16(p.kind == WIRE_KIND_WIRE ? EPI_GABOR_BWD_FIRST : EPI_GABOR2D_BWD_FIRST, n);
   const int64_t crp_set = (int64_t)(colreduce_blocks(n) + 32) * p.ldu * 5;   // wire2d: second set of partial sums
@@ -507,7 +566,8 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
                               p.P, wL, p.s, gcur, Sx + sc.fpw, Sx + sc.fpb));
     } else {
       HIPCHK(launch_final_bwd(s, p.kind, 0, g_y, n, p.O, packed + p.off_wf, lin_l(p.L), out_l(p.L),
-                              p.K, p.P, wL, p.s, gcur, Sx + sc.fpw, Sx + sc.fpb));
+                              p.K, p.P, wL, p.s, gcur, Sx + sc.fpw, Sx + sc.fpb,
+                              x2 ? gamax + p.L * WIRE_AMAX_SLOTS : nullptr));
     }
     HIPCHK(launch_final_reduce(s, p.kind, Sx + sc.fpw, Sx + sc.fpb, nbf, p.O, p.K, p.P,
                                (float*)grads[p.ntens - 2], (float*)grads[p.ntens - 1]));
@@ -543,7 +603,10 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
     } else {
       const int S = p.x3 ? gemmx3_tn_splits(n, p.Pl, p.P, sc.S) : gemm_tn_splits(n, p.Pl, p.P, sc.S);
       { ProfScope ps(s, 2, 2.0 * n * p.Pl * p.P);
-        if (p.x3)
+        if (x2 && gemmx2_tn_applies(p.Pl, p.P))
+          HIPCHK(launch_gemmx2_tn(s, gcur, p.Pl, out_l(l - 1), p.P, n, p.Pl, p.P, S, Sx + sc.slab, Sx + sc.bslab,
+                                  gamax + l * WIRE_AMAX_SLOTS, amax + (l - 1) * WIRE_AMAX_SLOTS));
+        else if (p.x3)
           HIPCHK(launch_gemmx3_tn(s, gcur, p.Pl, out_l(l - 1), p.P, n, p.Pl, p.P, S, Sx + sc.slab,
                                   Sx + sc.bslab));
         else
@@ -578,7 +641,11 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
     }
     if (!p.cplx && l == 1) ep.ld0 = p.P;
     { ProfScope ps(s, 1, 2.0 * n * p.Pl * p.P);
-      if (p.m3)
+      if (x2) {
+        ep.amax_a = gamax + l * WIRE_AMAX_SLOTS; ep.amax_b = wamax(l);
+        ep.amax_out = l >= 2 ? gamax + (l - 1) * WIRE_AMAX_SLOTS : nullptr;   // g_lin_0 feeds no 2 x fp16 GEMM
+        HIPCHK(launch_gemmx2h_nt(s, epi, gcur, p.Pl, packed + p.off_dg_x2[l], n, p.P, p.Pl, ep));
+      } else if (p.m3)
         HIPCHK(launch_gemm3m_nt(s, epi, gcur, p.P, packed + p.off_dg_3m[l], p.P, n, p.Kp, p.Kp, ep));
       else if (p.x3)
         HIPCHK(launch_gemmx3_nt(s, epi, gcur, p.Pl, packed + p.off_dg_x3[l], n, p.P, p.Pl, ep));
@@ -670,9 +737,13 @@ extern "C" int wire_train_fwd_bwd(void* stream, const wire_net_desc* d, const fl
     // one pass over out_L / lin_L instead of three
     ProfScope ps(s, 3, 0);
     const float* linL = p.kind == WIRE_KIND_RELU ? nullptr : A + a.lin1 + (int64_t)(p.L - 1) * n * p.Pl;
+    const bool x2 = use_x2(p, n);
+    unsigned* const gamax = reinterpret_cast<unsigned*>(Sx + sc.gamax);
+    if (x2) HIPCHK(hipMemsetAsync(gamax, 0, (size_t)(p.L + 2) * WIRE_AMAX_SLOTS * sizeof(unsigned), s));
     HIPCHK(launch_final_fused(s, p.kind, recomp ? nullptr : A + a.out0 + (int64_t)p.L * n * p.P, linL, n, p.P, p.O,
                               p.K, packed + p.off_wf, packed + p.off_bf, target, idx, first, weight,
-                              p.w, p.s, y, rec, Sx + sc.ga, Sx + sc.fpw, Sx + sc.fpb, Sx + sc.crp, loss_out));
+                              p.w, p.s, y, rec, Sx + sc.ga, Sx + sc.fpw, Sx + sc.fpb, Sx + sc.crp, loss_out,
+                              x2 ? gamax + p.L * WIRE_AMAX_SLOTS : nullptr));
   }
   return mlp_bwd_core(stream, p, packed, coords, n, nullptr, act, act_bytes, scratch, scratch_bytes, grads, false);
 }

@@ -208,3 +208,38 @@ WIRE_DEVINL void gabor2d_fwd_lean(float u, float v, float p, float q, float w0, 
   o_re = e * cs;
   o_im = e * sn;
 }
+
+// ---- power-of-two operand scales of the 2 x fp16 split GEMMs (wire_gemmx2h.hip) ------------------------------
+// Every tensor that such a GEMM reads as an operand has WIRE_AMAX_SLOTS sharded slots holding the bit pattern of its
+// max |value| (unsigned compare = float compare for non-negative floats), filled by its producer with atomicMax and
+// zeroed by the host sequence beforehand.  The consumer maps the maximum into [2^14, 2^15) -- below the fp16 overflow
+// limit 65504, far above the fp16 subnormal range -- by an exact power of two.
+#define WIRE_AMAX_SLOTS 64
+WIRE_DEVINL void wire_amax_publish(unsigned* slots, float m, int lane) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o));
+  if (lane == 0) {
+    const unsigned bits = __float_as_uint(m);
+    unsigned* slot = slots + (blockIdx.x & (WIRE_AMAX_SLOTS - 1));
+    // a stale (smaller) value only costs a redundant atomic: the maximum is monotone
+    if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+  }
+}
+// every lane returns the maximum over the slots (the producer finished at a kernel boundary)
+WIRE_DEVINL unsigned wire_amax_read(const unsigned* slots, int lane) {
+  unsigned m = slots[lane & (WIRE_AMAX_SLOTS - 1)];
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    const unsigned t = (unsigned)__shfl_xor((int)m, o);
+    m = m > t ? m : t;
+  }
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+}
+// scale 2^(14 - e) for a maximum in [2^e, 2^(e+1)) and its inverse; 1 for an all-zero, subnormal-only, vanishing
+// (< 2^-112) or non-finite tensor
+WIRE_DEVINL void wire_x2_scales(unsigned maxbits, float& s, float& inv) {
+  const int E = (int)(maxbits >> 23);
+  if (E < 15 || E > 254) { s = 1.f; inv = 1.f; return; }
+  s = __uint_as_float((unsigned)(268 - E) << 23);
+  inv = __uint_as_float((unsigned)(E - 14) << 23);
+}

@@ -40,6 +40,10 @@ struct GemmEpiParams {
   int64_t cr_set = 0;            //   wire2d: floats between the sums of the layer's two Linears (g_u, g_p)
   int recompute_out = 0;         // EPI_GABOR_BWD of wire_gemmx3h.hip: out = act(lin) again instead of reading i1
   int stagger = 0, stagger_lo = 0, stagger_hi = 0;   // wire_gemmx3g.hip: late start (100 MHz ticks) of blocks [lo, hi)
+  // 2 x fp16 split GEMM (wire_gemmx2h.hip): sharded max-|value| slots (WIRE_AMAX_SLOTS unsigned each, wire_dev.h)
+  const unsigned* amax_a = nullptr;   //   of the activation operand A (filled by A's producer)
+  const unsigned* amax_b = nullptr;   //   of the weight image (filled by launch_amax over the fp32 image)
+  unsigned* amax_out = nullptr;       //   of the tensor this epilogue writes for the next GEMM (out / g_lin); may be null
 #ifdef WIRE_ABLATE
   int ablate = 0;                // tools/gemm_tune only: 1 no global loads, 2 no LDS writes, 4 no barrier
 #endif
@@ -101,3 +105,21 @@ int gemmx3h_tune_set(const char* key, int value);
 int gemmx3h_mode();
 hipError_t launch_gemmx3h_nt(hipStream_t s, int epi, const float* A, int lda, const void* Bx3, int64_t M,
                              int Nc, int Kd, const GemmEpiParams& ep);
+
+// ---- 2 x fp16 split GEMMs on v_mfma_f32_16x16x32_f16 (wire_gemmx2h.hip): 3 partial products per fp32 product, operands
+// scaled by powers of two taken from their producers' max-|value| slots (WIRE_AMAX_SLOTS unsigned per tensor, wire_dev.h)
+#define X2_AMAX_MAXB 32
+struct X2AmaxBatch { const float* src[X2_AMAX_MAXB]; unsigned* slots[X2_AMAX_MAXB]; };
+hipError_t launch_amax_batch(hipStream_t s, const X2AmaxBatch& ab, int nb, int64_t count);
+hipError_t launch_amax(hipStream_t s, const float* src, int64_t count, unsigned* slots);
+int64_t gemmx2_b_image_floats(int Nc, int Kd);
+#define X2_SPLIT_MAXB 32
+struct X2SplitBatch { const float* src[X2_SPLIT_MAXB]; void* dst[X2_SPLIT_MAXB]; const unsigned* slots[X2_SPLIT_MAXB]; };
+hipError_t launch_x2_split_b_batch(hipStream_t s, const X2SplitBatch& sb, int nb, int ldb, int Nc, int Kd);
+hipError_t launch_gemmx2h_nt(hipStream_t s, int epi, const float* A, int lda, const void* Bx2, int64_t M, int Nc,
+                             int Kd, const GemmEpiParams& ep);
+int gemmx2h_tune_set(const char* key, int value);
+bool gemmx2_tn_applies(int Pm, int Pn);
+hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n, int Pm,
+                            int Pn, int splits, float* slab, float* bslab, const unsigned* amax_g,
+                            const unsigned* amax_z);

@@ -1,0 +1,638 @@
+// wire_gemmx2h.hip -- the layer GEMMs of the WIRE hot path as a TWO-way fp16 split on v_mfma_f32_16x16x32_f16.
+//
+// Arithmetic.  Every fp32 operand x is scaled by a power of two s (exact) and split into two fp16 terms,
+//     x s = h + l,   h = fp16(x s),  l = fp16(x s - h)        (round-to-nearest at both levels: |x s - h - l| <= 2^-24 |x s|,
+//                                                               one bit short of fp32's own 24)
+// and a product is accumulated from the three partial products of weight >= 2^-12 of the leading one:
+//     a b  ~=  a_h b_l + a_l b_h + a_h b_h                     (dropped: a_l b_l <= 2^-22 |a b|)
+// Each partial product of two fp16 numbers is exact in fp32 and the MFMA accumulates in fp32.  Measured against fp64
+// (tools/f16x2_numerics.hip, profiles/r03_f16x2_numerics.txt; K = 512, five data distributions including gradient-like
+// 1e-7-magnitude operands): rms error 0.64 - 0.78 x that of the exact-fp32 MFMA chain (v_mfma_f32_32x32x2_f32) and
+// 0.76 - 0.80 x that of the six-product 3 x bf16 split of wire_gemmx3.hip -- fp32 arithmetic in the sense of the parity
+// protocol, at HALF the matrix-core work of the 3 x bf16 split (3 instead of 6 MFMAs per fp32 product).
+//
+// Range.  fp16 has 5 exponent bits, so the scale matters: s maps the operand tensor's max |value| into [2^14, 2^15)
+// (wire_dev.h: wire_x2_scales).  Then h is normal for every element within 2^-28 of the maximum and the error of an
+// element is max(2^-24 |x|, 2^-39 max|x|) (l subnormal: gfx950's f16 MFMA honours subnormal inputs -- probed; were they
+// flushed the floor would be 2^-28 max|x|, still below fp32's own epsilon relative to the maximum).  The maximum of each
+// operand tensor is tracked by its PRODUCER (wire_gemmh_epi.h epilogues, first_fwd_kernel, final_fused_kernel: one
+// atomicMax per wave into 64 sharded slots) and read at the consumer's start: no host round trip.  Results are
+// multiplied by 1 / (s_A s_B) in the epilogue (exact).
+//
+// NT kernel (forward and data gradient), C[M][Nc] = A[M][Kd] Bt[Nc][Kd]^T + fused epilogue:
+//  * 256 x 128 tile, 4 waves stacked in M (64 rows x 128 columns each), stages of 32 reduction indices: one MFMA
+//    covers the 32 k of a stage for ONE partial product -- three 16-cycle instructions per 16 x 16 block and stage,
+//    against six (as three paired ones per 16 k) in wire_gemmx3h.hip;
+//  * A: fp32 rows by LDS-DMA into a WAVE-PRIVATE, single-buffered 8 KB region (a wave reads its own 64 rows into
+//    registers at the top of a stage and then immediately refills the region for the next stage: no barrier, no second
+//    buffer), split in registers: 24 vector ops per 16-row block and stage (v_cvt_pk_f16_f32, v_fma_mix_f32), every
+//    lane productive -- 96 per wave and 32 k where the 3 x bf16 kernel spends 224;
+//  * B: the pre-split weight image (x2_split_b_kernel), two 8 KB planes per stage, double-buffered by LDS-DMA; the
+//    image is stored in FRAGMENT order [16-column block][k slot][column][8 k], so a fragment read is lane * 16 bytes
+//    (conflict-free, one address register) and a DMA piece is 1 KB as it lies;
+//  * LDS 64 KB -> 2 workgroups per CU; one s_barrier per stage;
+//  * epilogues: wire_gemmh_epi.h (shared with wire_gemmx3h.hip), with the scale and the maximum tracking.
+//
+// Replaces the ATen complex addmm / mm of modules/wire.py:89 and of its autograd backward (and the real addmm of
+// modules/siren.py:49, gauss.py:28, relu.py:29, wire2d.py:57-58) at M >= 4096.
+#include <cstdlib>
+#include <cstring>
+
+#include "wire_dev.h"
+#include "wire_gemm.h"
+#include "wire_gemmh_epi.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned x2u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned x2u32x2 __attribute__((ext_vector_type(2)));
+
+#define X2_BK 32
+#define X2_TBM 256
+#define X2_TBN 128
+#define X2_AWAVE (64 * 128)            // a wave's private A region: 64 rows x 32 k fp32
+#define X2_ABYTES (4 * X2_AWAVE)
+#define X2_BPLANE (X2_TBN * 64)        // 128 columns x 32 k fp16
+#define X2_BSTAGE (2 * X2_BPLANE)      // planes h, l
+#ifndef X2_PFD
+#define X2_PFD 3                       // AMODE 2: stages of L2 prefetch distance
+#endif
+
+WIRE_DEVINL unsigned x2_cvt_pk(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));     // v_cvt_pk_f16_f32 (round to nearest)
+}
+// (x0, x1) s = H + L in packed fp16 pairs (low half = first element): 6 vector ops
+WIRE_DEVINL void x2_split2(float x0, float x1, float s, unsigned& H, unsigned& L) {
+  H = x2_cvt_pk(x0 * s, x1 * s);
+  float r0, r1;
+  // x s - h in one instruction each: the fp16 half is converted on the fly, the product is not rounded
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x0), "v"(s), "v"(H));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x1), "v"(s), "v"(H));
+  L = x2_cvt_pk(r0, r1);
+}
+
+#define X2_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+
+WIRE_DEVINL void x2_dma16(const void* gsrc, unsigned char* lds_piece) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
+}
+
+// ---------------------------------------------------------------------------
+// max |value| of a tensor into its sharded slots (weights once per optimizer step; activations of the per-layer API)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void amax_batch_kernel(X2AmaxBatch ab, long long count) {
+  const float* __restrict__ src = ab.src[blockIdx.y];
+  float m = 0.f;
+  const long long n4 = count >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+    h_amax4(m, *reinterpret_cast<const f32x4*>(src + 4 * i));
+  if (blockIdx.x == 0 && threadIdx.x < (count & 3)) m = __builtin_fmaxf(m, __builtin_fabsf(src[4 * n4 + threadIdx.x]));
+  wire_amax_publish(ab.slots[blockIdx.y], m, threadIdx.x & 63);
+}
+hipError_t launch_amax_batch(hipStream_t s, const X2AmaxBatch& ab, int nb, int64_t count) {
+  if (nb < 1 || nb > X2_AMAX_MAXB || count < 0) return hipErrorInvalidValue;
+  if (count == 0) return hipSuccess;
+  long long blocks = (count / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(amax_batch_kernel, dim3((unsigned)blocks, nb), dim3(256), 0, s, ab, (long long)count);
+  return hipGetLastError();
+}
+hipError_t launch_amax(hipStream_t s, const float* src, int64_t count, unsigned* slots) {
+  X2AmaxBatch ab{};
+  ab.src[0] = src; ab.slots[0] = slots;
+  return launch_amax_batch(s, ab, 1, count);
+}
+
+// ---------------------------------------------------------------------------
+// weights: fp32 image Bt[Nc][ldb] -> scaled, split, fragment-ordered fp16 image
+//   Bx2[col tile ct][stage kt (32 k)][plane (h, l)][16-col block cb (8)][k slot ks (4)][col (16)][8 k]
+// so that the 16 KB of one (tile, stage) are contiguous and lie as the GEMM's LDS stage does.  Columns >= Nc of the last
+// tile are zero.
+// ---------------------------------------------------------------------------
+__global__ void x2_split_b_batch_kernel(X2SplitBatch sb, int ldb, int Nc, int Kd, int nk) {
+  const float* __restrict__ Bt = sb.src[blockIdx.z];
+  unsigned short* __restrict__ Bx2 = (unsigned short*)sb.dst[blockIdx.z];
+  float s, inv;
+  wire_x2_scales(wire_amax_read(sb.slots[blockIdx.z], threadIdx.x & 63), s, inv);
+  const int k2 = (blockIdx.x * blockDim.x + threadIdx.x) * 2;   // pair of reduction indices
+  const int j = blockIdx.y;                                     // column, < tiles_n * 128
+  if (k2 >= Kd) return;
+  float x0 = 0.f, x1 = 0.f;
+  if (j < Nc) { x0 = Bt[(size_t)j * ldb + k2]; x1 = Bt[(size_t)j * ldb + k2 + 1]; }
+  unsigned H, L;
+  x2_split2(x0, x1, s, H, L);
+  const int ct = j >> 7, c = j & 127, cb = c >> 4, col = c & 15;
+  const int kt = k2 >> 5, kk = k2 & 31, ks = kk >> 3, k8 = kk & 7;
+  const size_t base = (((size_t)(ct * nk + kt) * 2) * 8 + cb) * 512 + (ks * 16 + col) * 8 + k8;
+  *reinterpret_cast<unsigned*>(Bx2 + base) = H;
+  *reinterpret_cast<unsigned*>(Bx2 + base + 8 * 512) = L;
+}
+int64_t gemmx2_b_image_floats(int Nc, int Kd) { return (int64_t)((Nc + 127) / 128) * 128 * Kd; }
+hipError_t launch_x2_split_b_batch(hipStream_t s, const X2SplitBatch& sb, int nb, int ldb, int Nc, int Kd) {
+  if ((Kd & 31) || nb < 1 || nb > X2_SPLIT_MAXB) return hipErrorInvalidValue;
+  const int tiles_n = (Nc + 127) / 128;
+  dim3 grid((unsigned)((Kd / 2 + 127) / 128), (unsigned)(tiles_n * 128), (unsigned)nb);
+  hipLaunchKernelGGL(x2_split_b_batch_kernel, grid, dim3(128), 0, s, sb, ldb, Nc, Kd, Kd / 32);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// NT GEMM
+// ---------------------------------------------------------------------------
+// AMODE 0: A through LDS as described above.  AMODE 1: A straight from global memory into the fragment registers of the
+// NEXT stage (8 global_load_dwordx4 per lane and stage, in flight under the MFMAs of the current one): no LDS-DMA pieces,
+// no LDS reads and no wait for them at the top of a stage for A; LDS holds the weight stages only (32 KB).
+template <int EPI, int AMODE>
+__global__ __launch_bounds__(256, 2) void gemmx2h_nt_kernel(const float* __restrict__ A, int lda,
+                                                            const unsigned short* __restrict__ Bx2, int M, int Nc,
+                                                            int Kd, int tiles_m, int tiles_n, GemmEpiParams ep) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[X2_ABYTES + 2 * X2_BSTAGE];   // (AMODE 1: the A part only serves the epilogues' reductions)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int b = blockIdx.x;
+  const int xcd = b & 7, idx = b >> 3;
+  const int ct = idx % tiles_n;
+  const int rt = (idx / tiles_n) * 8 + xcd;
+  if (rt >= tiles_m) return;
+  const int m_base = rt * X2_TBM, n_base = ct * X2_TBN;
+  const int nk = Kd / X2_BK;
+
+  // operand scales from the producers' maxima (uniform; a kernel boundary lies between the producers and this read)
+  float s_a, inv_a, s_b, inv_b;
+  wire_x2_scales(wire_amax_read(ep.amax_a, lane), s_a, inv_a);
+  wire_x2_scales(wire_amax_read(ep.amax_b, lane), s_b, inv_b);
+  (void)s_b;
+
+  // ---- DMA plan.  A: this wave's own 64 rows, 8 pieces of (16 rows x 64 bytes) per stage -- block rb, k half p: lane =
+  // (k slot inside the half, 16-byte half of the slot's 32 bytes, row) lands at [k slot][half][row][16 B] of the block,
+  // the order the fragment reads below walk.  Offsets are relative to the tile's first row (32-bit).
+  unsigned a_off[4];
+  {
+    const int r = lane & 15, hq = (lane >> 4) & 1, ksl = lane >> 5;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      int row = m_base + wave * 64 + rb * 16 + r;
+      row = row < M ? row : M - 1;
+      a_off[rb] = (unsigned)(row - m_base) * (unsigned)lda * 4u + (unsigned)(ksl * 32 + hq * 16);
+    }
+  }
+  const char* const a_tile = reinterpret_cast<const char*>(A + (size_t)m_base * lda);
+  // B: the 16 KB of a stage lie in the image as they do in LDS: piece q = wave + 4 j, 1 KB each
+  const char* const b_tile = reinterpret_cast<const char*>(Bx2) + (size_t)ct * nk * X2_BSTAGE;
+  const unsigned b_off = (unsigned)(wave * 1024 + lane * 16);
+  unsigned char* const a_lds = smem + wave * X2_AWAVE;
+  // AMODE 1: lane (row r = lane & 15, k slot ks = lane >> 4) loads its own 32 bytes of every block
+  unsigned g_off[4];
+  {
+    const int r = lane & 15, ks = lane >> 4;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      int row = m_base + wave * 64 + rb * 16 + r;
+      row = row < M ? row : M - 1;
+      g_off[rb] = (unsigned)(row - m_base) * (unsigned)lda * 4u + (unsigned)(ks * 32);
+    }
+  }
+  f32x4 araw[4][2];
+  auto aload = [&](int kt) {
+    const char* ab = a_tile + (size_t)kt * (X2_BK * 4);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      araw[rb][0] = *reinterpret_cast<const f32x4*>(ab + g_off[rb]);
+      araw[rb][1] = *reinterpret_cast<const f32x4*>(ab + g_off[rb] + 16);
+    }
+  };
+  // AMODE 2 = AMODE 1 + an L2 prefetch: a stage's 32 k of a row are exactly one 128-byte line, so one dword per lane
+  // (lane = row of the wave's 64) touches every line of stage kt + X2_PFD; it lands in a scratch LDS word via LDS-DMA (no
+  // register to clobber) and is the youngest memory operation of the stage, which the end-of-stage wait leaves in flight
+  unsigned pf_off;
+  {
+    int row = m_base + wave * 64 + lane;
+    row = row < M ? row : M - 1;
+    pf_off = (unsigned)(row - m_base) * (unsigned)lda * 4u;
+  }
+  auto prefetch = [&](int kt) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_tile + (size_t)kt * (X2_BK * 4) + pf_off),
+                                     (__attribute__((address_space(3))) void*)(smem + wave * 256), 4, 0, 0);
+  };
+  auto issue = [&](int kt, int buf) {
+    const char* ab = a_tile + (size_t)kt * (X2_BK * 4);
+    if constexpr (AMODE == 0) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        x2_dma16(ab + a_off[rb], a_lds + rb * 2048);
+        x2_dma16(ab + a_off[rb] + 64, a_lds + rb * 2048 + 1024);
+      }
+    }
+    const char* bb = b_tile + (size_t)kt * X2_BSTAGE;
+    unsigned char* S = smem + X2_ABYTES + buf * X2_BSTAGE + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x2_dma16(bb + b_off + j * 4096, S + j * 4096);
+  };
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses: A block rb: lane (row r = lane & 15, k slot ks = lane >> 4) reads its 32 bytes as two 16-byte
+  // pieces at [ks][0][r], [ks][1][r]; B block cb of a plane: lane * 16
+  const int a_rd = wave * X2_AWAVE + (lane >> 4) * 512 + (lane & 15) * 16;
+  const int b_rd = X2_ABYTES + lane * 16;
+  // the last column tile of a width that is no multiple of 128 (K = 212: 448) has 64 columns: skip the idle half
+  const bool half_tile = Nc - n_base <= 64;
+
+  issue(0, 0);
+  if constexpr (AMODE >= 1) aload(0);
+  if constexpr (AMODE == 2) {
+#pragma unroll
+    for (int d = 1; d < X2_PFD; ++d)
+      if (d < nk) prefetch(d);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if constexpr (AMODE == 0) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        araw[rb][0] = *reinterpret_cast<const f32x4*>(smem + a_rd + rb * 2048);
+        araw[rb][1] = *reinterpret_cast<const f32x4*>(smem + a_rd + rb * 2048 + 256);
+      }
+      // the region is refilled right away: every read of it must have returned
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    f16x8 ah[4], al[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      unsigned H[4], L[4];
+      x2_split2(araw[rb][0][0], araw[rb][0][1], s_a, H[0], L[0]);
+      x2_split2(araw[rb][0][2], araw[rb][0][3], s_a, H[1], L[1]);
+      x2_split2(araw[rb][1][0], araw[rb][1][1], s_a, H[2], L[2]);
+      x2_split2(araw[rb][1][2], araw[rb][1][3], s_a, H[3], L[3]);
+      ah[rb] = __builtin_bit_cast(f16x8, x2u32x4{H[0], H[1], H[2], H[3]});
+      al[rb] = __builtin_bit_cast(f16x8, x2u32x4{L[0], L[1], L[2], L[3]});
+    }
+    if constexpr (AMODE >= 1) {
+      // the raw registers are free again: next stage's rows and weight pieces go out under this stage's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) { issue(kt + 1, buf ^ 1); aload(kt + 1); }
+      if constexpr (AMODE == 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch(kt + X2_PFD < nk ? kt + X2_PFD : nk - 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const unsigned char* S = smem + b_rd + buf * X2_BSTAGE;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      if (hb == 1 && half_tile) break;
+      f16x8 bh[4], bl[4];
+#pragma unroll
+      for (int cq = 0; cq < 4; ++cq) {
+        bh[cq] = *reinterpret_cast<const f16x8*>(S + (4 * hb + cq) * 1024);
+        bl[cq] = *reinterpret_cast<const f16x8*>(S + X2_BPLANE + (4 * hb + cq) * 1024);
+      }
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) {
+          // small terms first; operands swapped (weights first): the block comes out transposed, four consecutive
+          // columns per lane (wire_gemmh_epi.h)
+          X2_MFMA(bl[cq], ah[rb], acc[rb][4 * hb + cq]);
+          X2_MFMA(bh[cq], al[rb], acc[rb][4 * hb + cq]);
+          X2_MFMA(bh[cq], ah[rb], acc[rb][4 * hb + cq]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (AMODE == 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    buf ^= 1;
+  }
+  h_epilogue<EPI, true>(acc, ep, M, m_base + wave * 64, n_base, Nc, lane, smem, wave, rt, inv_a * inv_b);
+}
+
+static int x2_env(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+static int g_x2_amode = x2_env("WIRE_X2_AMODE", 0);
+int gemmx2h_tune_set(const char* key, int value) {
+  if (!strcmp(key, "x2_amode") && value >= 0 && value <= 2) { g_x2_amode = value; return 0; }
+  return -1;
+}
+
+template <int EPI>
+static hipError_t launchx2h_t(hipStream_t s, const float* A, int lda, const unsigned short* Bx2, int64_t M, int Nc,
+                              int Kd, const GemmEpiParams& ep) {
+  const int tiles_m = (int)((M + X2_TBM - 1) / X2_TBM);
+  const int tiles_n = (Nc + X2_TBN - 1) / X2_TBN;
+  const int tiles_m_pad = (tiles_m + 7) & ~7;
+  if (g_x2_amode == 2)
+    hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 2>), dim3((unsigned)(tiles_m_pad * tiles_n)), dim3(256), 0, s, A, lda, Bx2,
+                       (int)M, Nc, Kd, tiles_m, tiles_n, ep);
+  else if (g_x2_amode == 1)
+    hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 1>), dim3((unsigned)(tiles_m_pad * tiles_n)), dim3(256), 0, s, A, lda, Bx2,
+                       (int)M, Nc, Kd, tiles_m, tiles_n, ep);
+  else
+    hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 0>), dim3((unsigned)(tiles_m_pad * tiles_n)), dim3(256), 0, s, A, lda, Bx2,
+                       (int)M, Nc, Kd, tiles_m, tiles_n, ep);
+  return hipGetLastError();
+}
+
+// Bx2: the image of launch_x2_split_b_batch; ep.amax_a / ep.amax_b: the operands' maximum slots
+hipError_t launch_gemmx2h_nt(hipStream_t s, int epi, const float* A, int lda, const void* Bx2v, int64_t M, int Nc,
+                             int Kd, const GemmEpiParams& ep) {
+  if (M <= 0) return hipSuccess;
+  if ((Nc & 63) || (Kd & 31) || (lda & 3) || M > 0x7fffff00LL || !ep.amax_a || !ep.amax_b) return hipErrorInvalidValue;
+  // 32-bit row offsets inside a 256-row tile
+  if ((int64_t)lda * 4 * X2_TBM > 0x7fffffffLL) return hipErrorInvalidValue;
+  const unsigned short* Bx2 = (const unsigned short*)Bx2v;
+  switch (epi) {
+    case EPI_STORE: return launchx2h_t<EPI_STORE>(s, A, lda, Bx2, M, Nc, Kd, ep);
+    case EPI_GABOR_FWD: return launchx2h_t<EPI_GABOR_FWD>(s, A, lda, Bx2, M, Nc, Kd, ep);
+    case EPI_GABOR_BWD: return launchx2h_t<EPI_GABOR_BWD>(s, A, lda, Bx2, M, Nc, Kd, ep);
+    case EPI_GABOR_BWD_FIRST: return launchx2h_t<EPI_GABOR_BWD_FIRST>(s, A, lda, Bx2, M, Nc, Kd, ep);
+    case EPI_SIREN_FWD: return launchx2h_t<EPI_SIREN_FWD>(s, A, lda, Bx2, M, Nc, Kd, ep);
+    case EPI_GAUSS_FWD: return launchx2h_t<EPI_GAUSS_FWD>(s, A, lda, Bx2, M, Nc, Kd, ep);
+    case EPI_RELU_FWD: return launchx2h_t<EPI_RELU_FWD>(s, A, lda, Bx2, M, Nc, Kd, ep);
+    case EPI_SIREN_BWD: return launchx2h_t<EPI_SIREN_BWD>(s, A, lda, Bx2, M, Nc, Kd, ep);
+    case EPI_GAUSS_BWD: return launchx2h_t<EPI_GAUSS_BWD>(s, A, lda, Bx2, M, Nc, Kd, ep);
+    case EPI_RELU_BWD: return launchx2h_t<EPI_RELU_BWD>(s, A, lda, Bx2, M, Nc, Kd, ep);
+    case EPI_GABOR2D_FWD:
+      if (Nc & 127) return hipErrorInvalidValue;
+      return launchx2h_t<EPI_GABOR2D_FWD>(s, A, lda, Bx2, M, Nc, Kd, ep);
+    case EPI_GABOR2D_BWD: return launchx2h_t<EPI_GABOR2D_BWD>(s, A, lda, Bx2, M, Nc, Kd, ep);
+    case EPI_GABOR2D_BWD_FIRST: return launchx2h_t<EPI_GABOR2D_BWD_FIRST>(s, A, lda, Bx2, M, Nc, Kd, ep);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// TN GEMM (weight gradient): slab[s] = G[rows_s]^T Z[rows_s], 256 x 256 features per workgroup of 8 waves -- the
+// 2 x fp16 edition of gemmx3_tn16_kernel (wire_gemmx3.hip), same structure:
+//  * the loader splits every fp32 value of a stage once (6 vector ops per 2 values) and stores two fp16 planes per
+//    operand in the [16-feature block][row slot][32 bytes] layout whose transposed fragment reads (ds_read_b64_tr_b16)
+//    and loader stores are 256-byte runs per half wave;
+//  * stages of 32 rows: the h h product takes the 32 rows of a stage in ONE 16 x 16 x 32 MFMA (rows 8 g .. 8 g + 7 in
+//    lane group g); the two small products ride together as plane PAIRS in the two k halves of an instruction, once per
+//    16 rows:  Z (h | l) x G (l | h) -> h l + l h.  Three MFMAs per 16 x 16 block and 32 rows (six in the 3 x bf16 kernel).
+//    Row slot of row r: (r & 3) | ((r >> 3) & 3) << 2 | ((r >> 2) & 1) << 4 -- every fragment address is the lane's base
+//    plus an immediate (+ 512: rows + 4; + 256: rows + 16; + 1024: next feature block);
+//  * 2 x 64 KB stage buffers, one workgroup per CU; waves 0-3 / 4-7 (the two waves of each SIMD) half a stage apart;
+//  * G and Z carry their own power-of-two scales (maximum slots of their producers); the slabs are unscaled on the way out.
+// ---------------------------------------------------------------------------
+typedef short x2s16x4 __attribute__((ext_vector_type(4)));
+#define X2T_TK 32
+#define X2T_PLANE (X2T_TK * 512)                // bytes of one 256-feature fp16 plane of a stage
+#define X2T_STAGE (4 * X2T_PLANE)               // G h, l then Z h, l
+
+WIRE_DEVINL x2s16x4 x2_lds_tr16(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (x2s16x4 __attribute__((address_space(3)))*)(const_cast<unsigned char*>(p)));
+}
+
+__global__ __launch_bounds__(512, 2) void gemmx2_tn16_kernel(
+    const float* __restrict__ G, int ldg, const float* __restrict__ Z, int ldz, long long n, int Pm, int Pn,
+    int tiles_n, int nsplit, long long chunk, float* __restrict__ slab, float* __restrict__ bslab, int tiles,
+    const unsigned* __restrict__ amax_g, const unsigned* __restrict__ amax_z) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave >> 1, wave_n = wave & 1;     // 64 features of G x 128 features of Z per wave
+  const int bb = blockIdx.x;
+  const int xcd = bb & 7, idx = bb >> 3;
+  const int tile = idx % tiles;
+  const int split = (idx / tiles) * 8 + xcd;
+  if (split >= nsplit) return;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m_base = tm * 256, n_base = tn * 256;
+  const long long row0 = (long long)split * chunk;
+  long long row1 = row0 + chunk;
+  if (row1 > n) row1 = n;
+  if (row1 <= row0) return;
+
+  float s_g, inv_g, s_z, inv_z;
+  wire_x2_scales(wire_amax_read(amax_g, lane), s_g, inv_g);
+  wire_x2_scales(wire_amax_read(amax_z, lane), s_z, inv_z);
+
+  // loader: wave w owns feature blocks 2w, 2w + 1 of both operands; a lane = (block half, row slot 0-7, quad p);
+  // pass t = 0..3 writes slots 8 t + (0-7), i.e. rows {0-3, 8-11}, {16-19, 24-27}, {4-7, 12-15}, {20-23, 28-31}
+  const int l_fb = 2 * wave + (lane >> 5), l_rs = (lane >> 2) & 7, l_p = lane & 3;
+  const int l_feat = 16 * l_fb + 4 * l_p;
+  const int l_st = l_fb * 1024 + l_rs * 32 + l_p * 8;   // + 256 per pass
+  // row of pass t = l_row0 + {0, 16, 4, 20}: the pass offsets are wave-uniform and fold into the scalar base
+  const int l_row0 = (l_rs & 3) + 8 * (l_rs >> 2);
+  constexpr int pass_row[4] = {0, 16, 4, 20};
+  const bool do_bias = (bslab != nullptr) && (tn == 0);
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+  const int nrows = (int)(row1 - row0);
+  const int nk = (nrows + X2T_TK - 1) / X2T_TK;
+  const int nk_full = nrows / X2T_TK;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  struct Staged { f32x4 g[4], z[4]; };
+  Staged st;
+  const unsigned g_off = (unsigned)l_row0 * (unsigned)ldg + (unsigned)(m_base + l_feat);
+  const unsigned z_off = (unsigned)l_row0 * (unsigned)ldz + (unsigned)(n_base + l_feat);
+  const float* const g_base = G + (size_t)row0 * ldg;
+  const float* const z_base = Z + (size_t)row0 * ldz;
+  auto gload = [&](Staged& R, int kt) {
+    int ks = kt < nk_full ? kt : nk_full - 1;
+    ks = ks < 0 ? 0 : ks;
+    const float* gb = g_base + (size_t)ks * (X2T_TK * (size_t)ldg);
+    const float* zb = z_base + (size_t)ks * (X2T_TK * (size_t)ldz);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) R.g[t] = *reinterpret_cast<const f32x4*>(gb + (size_t)pass_row[t] * ldg + g_off);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) R.z[t] = *reinterpret_cast<const f32x4*>(zb + (size_t)pass_row[t] * ldz + z_off);
+  };
+  auto gload_tail = [&](Staged& R) {
+    const int rb = nk_full * X2T_TK;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = rb + l_row0 + pass_row[t];
+      R.g[t] = row < nrows ? *reinterpret_cast<const f32x4*>(g_base + (size_t)row * ldg + m_base + l_feat) : zero4;
+      R.z[t] = row < nrows ? *reinterpret_cast<const f32x4*>(z_base + (size_t)row * ldz + n_base + l_feat) : zero4;
+    }
+  };
+  auto lstore = [&](const Staged& R, int buf) {
+    unsigned char* S = smem_t + buf * X2T_STAGE + l_st;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 gv = R.g[t];
+      unsigned h0, l0, h1, l1;
+      x2_split2(gv[0], gv[1], s_g, h0, l0);
+      x2_split2(gv[2], gv[3], s_g, h1, l1);
+      unsigned char* d = S + t * 256;
+      *reinterpret_cast<x2u32x2*>(d) = x2u32x2{h0, h1};
+      *reinterpret_cast<x2u32x2*>(d + X2T_PLANE) = x2u32x2{l0, l1};
+      if (do_bias) { bsum[0] += gv[0]; bsum[1] += gv[1]; bsum[2] += gv[2]; bsum[3] += gv[3]; }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 zv = R.z[t];
+      unsigned h0, l0, h1, l1;
+      x2_split2(zv[0], zv[1], s_z, h0, l0);
+      x2_split2(zv[2], zv[3], s_z, h1, l1);
+      unsigned char* d = S + 2 * X2T_PLANE + t * 256;
+      *reinterpret_cast<x2u32x2*>(d) = x2u32x2{h0, h1};
+      *reinterpret_cast<x2u32x2*>(d + X2T_PLANE) = x2u32x2{l0, l1};
+    }
+  };
+
+  // fragment reads (plane order in LDS: G h, G l, Z h, Z l)
+  const int hi = lane >> 5;
+  const int g_hh = lane * 8 + wave_m * (4 * 1024);
+  const int g_pr = (lane & 31) * 8 + (hi ? 0 : 1) * X2T_PLANE + wave_m * (4 * 1024);                    // G (l | h)
+  const int z_hh = 2 * X2T_PLANE + lane * 8 + wave_n * (8 * 1024);
+  const int z_pr = 2 * X2T_PLANE + (lane & 31) * 8 + (hi ? 1 : 0) * X2T_PLANE + wave_n * (8 * 1024);   // Z (h | l)
+
+  auto frag = [&](const unsigned char* p) {
+    const x2s16x4 a = x2_lds_tr16(p), b = x2_lds_tr16(p + 512);
+    return __builtin_bit_cast(f16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+
+  // two passes over the 8 Z blocks, so that at most 40 fragment registers are live beside the 128 accumulator and the
+  // 32 staging registers: the pair products (G pair fragments of the 4 blocks held), then h h (G h fragments held)
+  auto mfma_block = [&](const int buf) {
+    const unsigned char* S = smem_t + buf * X2T_STAGE;
+    {
+      f16x8 gp0[4], gp1[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        gp0[i] = frag(S + g_pr + i * 1024);
+        gp1[i] = frag(S + g_pr + 256 + i * 1024);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f16x8 zp0 = frag(S + z_pr + j * 1024);
+        const f16x8 zp1 = frag(S + z_pr + 256 + j * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          X2_MFMA(zp0, gp0[i], acc[i][j]);
+          X2_MFMA(zp1, gp1[i], acc[i][j]);
+        }
+      }
+    }
+    {
+      f16x8 ghh[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ghh[i] = frag(S + g_hh + i * 1024);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f16x8 zhh = frag(S + z_hh + j * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) X2_MFMA(zhh, ghh[i], acc[i][j]);
+      }
+    }
+  };
+  auto load_any = [&](const int sidx) {
+    if (sidx < nk_full) gload(st, sidx);
+    else if (sidx < nk) gload_tail(st);
+  };
+  // late (waves 0-3): loads of stage kt + 1 | MFMAs of stage kt | split + store stage kt + 1
+  // early (waves 4-7): split + store stage kt + 1 (loaded a stage ago) | loads of stage kt + 2 | MFMAs of stage kt
+  const bool early = wave >= 4;
+  load_any(0);
+  lstore(st, 0);
+  if (early) load_any(1);
+  __syncthreads();
+
+  auto stage = [&](const int kt, const bool fast) {
+    const int buf = kt & 1;
+    if (!early) {
+      if (fast) gload(st, kt + 1); else load_any(kt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(buf);
+      if (fast || kt + 1 < nk) lstore(st, buf ^ 1);
+    } else {
+      if (fast || kt + 1 < nk) lstore(st, buf ^ 1);
+      if (fast) gload(st, kt + 2); else load_any(kt + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(buf);
+    }
+    __syncthreads();
+  };
+  int kt = 0;
+  for (; kt + 2 < nk_full; ++kt) stage(kt, true);      // stages kt + 1 and kt + 2 are full ones
+  for (; kt < nk; ++kt) stage(kt, false);
+
+  if (do_bias) {
+    // the 8 row-slot lanes of a feature quad: sum through LDS (all fragment reads are done)
+    float* red = reinterpret_cast<float*>(smem_t);
+    *reinterpret_cast<f32x4*>(&red[l_rs * 256 + l_feat]) = bsum;
+    __syncthreads();
+    if (tid < 256) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v += red[r * 256 + tid];
+      bslab[(size_t)split * Pm + m_base + tid] = v;
+    }
+  }
+  // accumulator block (i, j): lane -> G feature 16 i + (lane & 15), Z features 16 j + 4 (lane >> 4) + q; blocks j, j + 1
+  // re-paired inside each 16-lane row (wire_gemmh_epi.h: h_pair_rows) -> whole 128-byte lines
+  float* out = slab + (size_t)split * Pm * Pn;
+  const float inv = inv_g * inv_z;
+  const int rr = lane & 7, cq = 16 * ((lane >> 3) & 1) + 4 * (lane >> 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m_base + wave_m * 64 + 16 * i + rr;
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+      f32x4 xp, yp;
+      h_pair_rows(acc[i][2 * jp], acc[i][2 * jp + 1], xp, yp);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { xp[q] *= inv; yp[q] *= inv; }
+      const int col = n_base + wave_n * 128 + 32 * jp + cq;
+      *reinterpret_cast<f32x4*>(out + (size_t)m * Pn + col) = xp;
+      *reinterpret_cast<f32x4*>(out + (size_t)(m + 8) * Pn + col) = yp;
+    }
+  }
+}
+
+bool gemmx2_tn_applies(int Pm, int Pn) { return Pm % 256 == 0 && Pn % 256 == 0; }
+
+// same split / chunk conventions as launch_gemmx3_tn (wire_gemmx3.hip): `splits` from gemmx3_tn_splits
+hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n, int Pm,
+                            int Pn, int splits, float* slab, float* bslab, const unsigned* amax_g,
+                            const unsigned* amax_z) {
+  if (!gemmx2_tn_applies(Pm, Pn) || (ldg & 3) || (ldz & 3) || splits < 1 || n < 1 || !amax_g || !amax_z)
+    return hipErrorInvalidValue;
+  const int tiles_m = Pm / 256, tiles_n = Pn / 256;
+  long long chunk = (n + splits - 1) / splits;
+  chunk = (chunk + 2 * X2T_TK - 1) / (2 * X2T_TK) * (2 * X2T_TK);
+  const int used = (int)((n + chunk - 1) / chunk);
+  const int splits_pad = (used + 7) & ~7;
+  dim3 grid((unsigned)(tiles_m * tiles_n * splits_pad));
+  if (used < splits) {   // slabs of unused splits must still be defined for the reduce kernels
+    hipError_t e = hipMemsetAsync(slab + (size_t)used * Pm * Pn, 0, (size_t)(splits - used) * Pm * Pn * 4, s);
+    if (e != hipSuccess) return e;
+    if (bslab) {
+      e = hipMemsetAsync(bslab + (size_t)used * Pm, 0, (size_t)(splits - used) * Pm * 4, s);
+      if (e != hipSuccess) return e;
+    }
+  }
+  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemmx2_tn16_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * X2T_STAGE);
+  if (attr != hipSuccess) return attr;
+  hipLaunchKernelGGL(gemmx2_tn16_kernel, grid, dim3(512), 2 * X2T_STAGE, s, G, ldg, Z, ldz, (long long)n, Pm, Pn,
+                     tiles_n, used, chunk, slab, bslab, tiles_m * tiles_n, amax_g, amax_z);
+  return hipGetLastError();
+}

@@ -25,7 +25,8 @@ hipError_t launch_pack_final(hipStream_t s, int kind, const float* Wf, const flo
 // out [n][P] blocked; lin (optional): real nets [n][P]; wire: real u [n][P/2] (per-layer API)
 hipError_t launch_first_fwd(hipStream_t s, int kind, const float* coords, int64_t n, int D,
                             const float* W0, const float* b0, const float* V0, const float* c0,
-                            int K, int P, float omega, float scale, float* lin, float* out);
+                            int K, int P, float omega, float scale, float* lin, float* out,
+                            unsigned* amax_out = nullptr);   // amax_out: max |out| slots (wire_dev.h) or null
 
 // ---- final linear: y[n][O] = z[n][P] . wf[O][P] + bf
 hipError_t launch_final_fwd(hipStream_t s, const float* z, int64_t n, int P, int O,
@@ -39,7 +40,7 @@ int final_bwd_blocks(int64_t n);
 hipError_t launch_final_bwd(hipStream_t s, int kind, int raw, const float* g_y, int64_t n, int O,
                             const float* wf, const float* lin, const float* out, int K, int P,
                             float omega, float scale, float* g_lin, float* part_w,
-                            float* part_b);
+                            float* part_b, unsigned* amax_g = nullptr);   // amax_g: max |g_lin| slots or null
 // part_w / part_b must have room for final_bwd_blocks(n) + 32 blocks (pre-reduction scratch)
 hipError_t launch_final_reduce(hipStream_t s, int kind, float* part_w, float* part_b,
                                int nblk, int O, int K, int P, float* gWf, float* gbf);
@@ -52,7 +53,7 @@ hipError_t launch_final_fused(hipStream_t s, int kind, const float* out, const f
                               int kvalid, const float* wf, const float* bfr, const float* target, const int64_t* idx,
                               int64_t first, float weight, float omega, float scale, float* y, float* rec,
                               float* g_lin, float* part_w, float* part_b, float* loss_partial,
-                              float* loss_out);
+                              float* loss_out, unsigned* amax_g = nullptr);   // amax_g: max |g_lin| slots or null
 
 // ---- weight-gradient slab reduction: slab[S][Pm][Pn] (+ bslab[S][Pm]) -> native grads
 hipError_t launch_wgrad_reduce(hipStream_t s, int kind, const float* slab, const float* bslab,

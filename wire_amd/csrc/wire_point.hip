@@ -132,12 +132,13 @@ __global__ void first_fwd_kernel(const float* __restrict__ coords, long long n, 
                                  const float* __restrict__ W0, const float* __restrict__ b0,
                                  const float* __restrict__ V0, const float* __restrict__ c0, int K,
                                  int P, float omega, float scale, float* __restrict__ lin,
-                                 float* __restrict__ out) {
+                                 float* __restrict__ out, unsigned* __restrict__ amax_out) {
   constexpr bool cplx = (KIND == NK_WIRE || KIND == NK_WIRE2D);
   const int nfeat = cplx ? (P >> 1) : P;
   const int f = blockIdx.y * blockDim.x + threadIdx.x;
-  if (f >= nfeat) return;
+  const bool live = f < nfeat;                  // (no early return: the maximum below is a whole-wave reduction)
   const bool valid = f < K;
+  float amx = 0.f;
   float w[4] = {0.f, 0.f, 0.f, 0.f}, wv[4] = {0.f, 0.f, 0.f, 0.f};
   float bb = 0.f, bv = 0.f;
   if (valid) {
@@ -162,30 +163,44 @@ __global__ void first_fwd_kernel(const float* __restrict__ coords, long long n, 
     if (KIND == NK_WIRE) {
       float o_re, o_im;
       gabor_fwd_real(u, omega, scale, o_re, o_im);
-      out[row * P + c_re] = valid ? o_re : 0.f;
-      out[row * P + c_re + 32] = valid ? o_im : 0.f;
-      if (lin) lin[row * nfeat + f] = valid ? u : 0.f;      // per-layer API only: real u, [n][P / 2]
+      o_re = valid ? o_re : 0.f; o_im = valid ? o_im : 0.f;
+      amx = __builtin_fmaxf(amx, __builtin_fmaxf(__builtin_fabsf(o_re), __builtin_fabsf(o_im)));
+      if (live) {
+        out[row * P + c_re] = o_re;
+        out[row * P + c_re + 32] = o_im;
+        if (lin) lin[row * nfeat + f] = valid ? u : 0.f;      // per-layer API only: real u, [n][P / 2]
+      }
     } else if (KIND == NK_WIRE2D) {
       float o_re, o_im;
       gabor2d_fwd(u, 0.f, p, 0.f, omega, scale, o_re, o_im);
-      out[row * P + c_re] = valid ? o_re : 0.f;
-      out[row * P + c_re + 32] = valid ? o_im : 0.f;
-      if (lin) {                                            // per-layer API only: real (u | p), [n][2 * P / 2]
-        lin[row * (2 * nfeat) + f] = valid ? u : 0.f;
-        lin[row * (2 * nfeat) + nfeat + f] = valid ? p : 0.f;
+      o_re = valid ? o_re : 0.f; o_im = valid ? o_im : 0.f;
+      amx = __builtin_fmaxf(amx, __builtin_fmaxf(__builtin_fabsf(o_re), __builtin_fabsf(o_im)));
+      if (live) {
+        out[row * P + c_re] = o_re;
+        out[row * P + c_re + 32] = o_im;
+        if (lin) {                                            // per-layer API only: real (u | p), [n][2 * P / 2]
+          lin[row * (2 * nfeat) + f] = valid ? u : 0.f;
+          lin[row * (2 * nfeat) + nfeat + f] = valid ? p : 0.f;
+        }
       }
     } else {
       constexpr int ACT = KIND - NK_SIREN;
-      const float o = real_act_fwd<ACT < 0 ? 0 : ACT>(u, omega, scale);
-      if (lin) lin[row * P + f] = valid ? u : 0.f;
-      out[row * P + f] = valid ? o : 0.f;
+      float o = real_act_fwd<ACT < 0 ? 0 : ACT>(u, omega, scale);
+      o = valid ? o : 0.f;
+      amx = __builtin_fmaxf(amx, __builtin_fabsf(o));
+      if (live) {
+        if (lin) lin[row * P + f] = valid ? u : 0.f;
+        out[row * P + f] = o;
+      }
     }
   }
+  // max |out_0| for the 2 x fp16 split GEMM that reads it (wire_gemmx2h.hip)
+  if (amax_out) wire_amax_publish(amax_out, amx, threadIdx.x & 63);
 }
 
 hipError_t launch_first_fwd(hipStream_t s, int kind, const float* coords, int64_t n, int D,
                             const float* W0, const float* b0, const float* V0, const float* c0,
-                            int K, int P, float omega, float scale, float* lin, float* out) {
+                            int K, int P, float omega, float scale, float* lin, float* out, unsigned* amax_out) {
   if (n <= 0) return hipSuccess;
   if (D > 4) return hipErrorInvalidValue;
   const bool cplx = (kind == NK_WIRE || kind == NK_WIRE2D);
@@ -194,7 +209,7 @@ hipError_t launch_first_fwd(hipStream_t s, int kind, const float* coords, int64_
   dim3 grid(cdiv(n, FIRST_ROWS), cdiv(nfeat, bx));
 #define FIRST_LAUNCH(KK)                                                                       \
   hipLaunchKernelGGL(first_fwd_kernel<KK>, grid, dim3(bx), 0, s, coords, (long long)n, D, W0, b0, \
-                     V0, c0, K, P, omega, scale, lin, out)
+                     V0, c0, K, P, omega, scale, lin, out, amax_out)
   switch (kind) {
     case NK_WIRE: FIRST_LAUNCH(NK_WIRE); break;
     case NK_WIRE2D: FIRST_LAUNCH(NK_WIRE2D); break;
@@ -267,9 +282,10 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(
     const float* __restrict__ g_y, long long n, int O, const float* __restrict__ wf,
     const float* __restrict__ lin, const float* __restrict__ out, int K, int P, float omega,
     float scale, float* __restrict__ g_lin, float* __restrict__ part_w,
-    float* __restrict__ part_b) {
+    float* __restrict__ part_b, unsigned* __restrict__ amax_g) {
   constexpr bool cplx = (KIND == NK_WIRE || KIND == NK_WIRE2D);
   __shared__ float sgy[FB_ROWS * MAXO];
+  float amx = 0.f;                                        // max |g_lin| for the 2 x fp16 split GEMMs that read it
   const long long r0 = (long long)blockIdx.x * FB_ROWS;
   long long r1 = r0 + FB_ROWS;
   if (r1 > n) r1 = n;
@@ -338,18 +354,22 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(
             gabor_bwd(gr, gi, l0[q], l1[q], pr[q], pi[q], omega, m2s2, gl_re, gl_im);
             g_lin[row * P + c0] = gl_re;
             g_lin[row * P + c0 + 32] = gl_im;
+            amx = __builtin_fmaxf(amx, __builtin_fmaxf(__builtin_fabsf(gl_re), __builtin_fabsf(gl_im)));
           } else if (KIND == NK_WIRE2D) {
             const float c_r = __builtin_fmaf(pr[q], gr, pi[q] * gi);
             const float c_i = __builtin_fmaf(pr[q], gi, -(pi[q] * gr));
             const float t = m2s2 * c_r;
             float* Gp = g_lin + row * Pl + lc;
-            Gp[0] = __builtin_fmaf(t, l0[q], omega * c_i);
-            Gp[32] = __builtin_fmaf(t, l1[q], -(omega * c_r));
-            Gp[64] = t * l2[q];
-            Gp[96] = t * l3[q];
+            const float g0 = __builtin_fmaf(t, l0[q], omega * c_i), g1 = __builtin_fmaf(t, l1[q], -(omega * c_r));
+            const float g2 = t * l2[q], g3 = t * l3[q];
+            Gp[0] = g0; Gp[32] = g1; Gp[64] = g2; Gp[96] = g3;
+            amx = __builtin_fmaxf(amx, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(g0), __builtin_fabsf(g1)),
+                                                       __builtin_fmaxf(__builtin_fabsf(g2), __builtin_fabsf(g3))));
           } else {
             constexpr int ACT = (KIND - NK_SIREN) < 0 ? 0 : (KIND - NK_SIREN);
-            g_lin[row * P + c0] = real_act_bwd<ACT>(gr, l0[q], pr[q], omega, scale);
+            const float gl = real_act_bwd<ACT>(gr, l0[q], pr[q], omega, scale);
+            g_lin[row * P + c0] = gl;
+            amx = __builtin_fmaxf(amx, __builtin_fabsf(gl));
           }
         }
       }
@@ -368,12 +388,13 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(
     for (int r = 0; r < nr; ++r) sacc += sgy[r * O + threadIdx.x];
     part_b[(size_t)blockIdx.x * O + threadIdx.x] = sacc;
   }
+  if (amax_g) wire_amax_publish(amax_g, amx, threadIdx.x & 63);
 }
 
 hipError_t launch_final_bwd(hipStream_t s, int kind, int raw, const float* g_y, int64_t n, int O,
                             const float* wf, const float* lin, const float* out, int K, int P,
                             float omega, float scale, float* g_lin, float* part_w,
-                            float* part_b) {
+                            float* part_b, unsigned* amax_g) {
   if (n <= 0) return hipSuccess;
   if (O > MAXO) return hipErrorInvalidValue;
   const bool cplx = (kind == NK_WIRE || kind == NK_WIRE2D);
@@ -381,7 +402,7 @@ hipError_t launch_final_bwd(hipStream_t s, int kind, int raw, const float* g_y, 
   dim3 grid((unsigned)final_bwd_blocks(n), cdiv(nfeat, 256));
 #define FB_LAUNCH(KK, RR)                                                                        \
   hipLaunchKernelGGL((final_bwd_kernel<KK, RR>), grid, dim3(256), 0, s, g_y, (long long)n, O, wf, \
-                     lin, out, K, P, omega, scale, g_lin, part_w, part_b)
+                     lin, out, K, P, omega, scale, g_lin, part_w, part_b, amax_g)
   if (raw) {
     if (cplx) FB_LAUNCH(NK_WIRE, true); else FB_LAUNCH(NK_RELU, true);
   } else {
@@ -428,14 +449,19 @@ bool final_fused_supported(int P, int O) {
 // OT >= O (1..FF_MAXO): the weight / partial-sum registers are sized for the actual number of outputs
 // RPW: rows per wave slot -- 2 when a row has at most 256 floats (siren / gauss / relu and wire2d at 256 features):
 // lanes 0-31 take one row, lanes 32-63 the next, instead of leaving half the wave idle
+WIRE_DEVINL void ff_amax4(float& m, const f32x4& v) {
+  m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])),
+                                         __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))));
+}
 template <int NPASS, int KIND, bool RECOMP, int OT, int RPW>
 __global__ __launch_bounds__(256) void final_fused_kernel(
     const float* __restrict__ out, const float* __restrict__ lin, long long n, int P, int O, int kvalid,
     const float* __restrict__ wf, const float* __restrict__ bfr, const float* __restrict__ target,
     const int64_t* __restrict__ idx, long long first, float gscale, float omega, float scale,
     float* __restrict__ y, float* __restrict__ rec, float* __restrict__ g_lin, float* __restrict__ part_w,
-    float* __restrict__ part_b, float* __restrict__ loss_partial, int rows_pb) {
+    float* __restrict__ part_b, float* __restrict__ loss_partial, int rows_pb, unsigned* __restrict__ amax_g) {
   static_assert(!RECOMP || KIND != NK_RELU, "relu keeps out and has no lin to recompute it from");
+  float amx = 0.f;                                     // max |g_lin| for the 2 x fp16 split GEMMs that read it
   static_assert(RPW == 1 || (RPW == 2 && NPASS == 1), "two rows per wave slot: one pass of at most 256 columns");
   constexpr int RL = 64 / RPW;                         // lanes of one row
   constexpr bool HAS_LIN = (KIND != NK_RELU);          // relu: lin is never stored (lin > 0 <=> out > 0)
@@ -610,6 +636,7 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
         }
         *reinterpret_cast<f32x4*>(Gp) = glr;
         *reinterpret_cast<f32x4*>(Gp + 32) = gli;
+        ff_amax4(amx, glr); ff_amax4(amx, gli);
       } else if (KIND == NK_WIRE2D) {
         // c = conj(out) g;  g_lin = -2 s^2 Re(c) lin - j w0 c;  g_sy = -2 s^2 Re(c) sy   (modules/wire2d.py:56-67)
         f32x4 g0, g1, g2, g3;
@@ -627,6 +654,7 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
         *reinterpret_cast<f32x4*>(Gp + 32) = g1;
         *reinterpret_cast<f32x4*>(Gp + 64) = g2;
         *reinterpret_cast<f32x4*>(Gp + 96) = g3;
+        ff_amax4(amx, g0); ff_amax4(amx, g1); ff_amax4(amx, g2); ff_amax4(amx, g3);
       } else {
         // the same forms final_bwd_kernel uses (sin'= w0 cos, gauss' = -2 s^2 lin out, relu' = [out > 0])
         constexpr int ACT = (KIND - NK_SIREN) < 0 ? 0 : (KIND - NK_SIREN);
@@ -638,6 +666,7 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
         }
         *reinterpret_cast<f32x4*>(Gp) = glr;
         *reinterpret_cast<f32x4*>(Gp + 32) = gli;
+        ff_amax4(amx, glr); ff_amax4(amx, gli);
       }
     }
   };
@@ -704,6 +733,7 @@ __global__ __launch_bounds__(256) void final_fused_kernel(
   if (threadIdx.x == 0)
     loss_partial[blockIdx.x] = (sb[FF_MAXO] + sb[(FF_MAXO + 1) + FF_MAXO]) +
                                (sb[2 * (FF_MAXO + 1) + FF_MAXO] + sb[3 * (FF_MAXO + 1) + FF_MAXO]);
+  if (amax_g) wire_amax_publish(amax_g, amx, lane);
 }
 
 // kind: NK_*.  out = nullptr (wire only): out_L is recomputed from lin_L (kvalid = number of valid complex
@@ -712,7 +742,7 @@ hipError_t launch_final_fused(hipStream_t s, int kind, const float* out, const f
                               int kvalid, const float* wf, const float* bfr, const float* target, const int64_t* idx,
                               int64_t first, float weight, float omega, float scale, float* y, float* rec,
                               float* g_lin, float* part_w, float* part_b, float* loss_partial,
-                              float* loss_out) {
+                              float* loss_out, unsigned* amax_g) {
   if (n <= 0) return hipSuccess;
   if (!final_fused_supported(P, O)) return hipErrorInvalidValue;
   if (!out && kind == NK_RELU) return hipErrorInvalidValue;
@@ -738,7 +768,7 @@ hipError_t launch_final_fused(hipStream_t s, int kind, const float* out, const f
 #define FF_LAUNCH(NP, RW, KD, RC, OT)                                                                        \
   hipLaunchKernelGGL((final_fused_kernel<NP, KD, RC, OT, RW>), dim3((unsigned)nblk), dim3(256), shm, s, out, \
                      lin, (long long)n, P, O, kvalid, wf, bfr, target, idx, (long long)first,                \
-                     weight * 2.f * inv, omega, scale, y, rec, g_lin, part_w, part_b, loss_partial, rows_pb)
+                     weight * 2.f * inv, omega, scale, y, rec, g_lin, part_w, part_b, loss_partial, rows_pb, amax_g)
 #define FF_LAUNCH_O(NP, RW, KD, RC)                                                                          \
   switch (O) {                                                                                               \
     case 1: FF_LAUNCH(NP, RW, KD, RC, 1); break;                                                             \

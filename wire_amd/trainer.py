@@ -40,6 +40,16 @@ class FusedTrainer:
                  coords_style: str = "torch", keep_rec: bool = False, micro_shards: int = 1,
                  group: Optional[dist.ProcessGroup] = None):
         self.L = _lib.lib()
+        # the fused step runs net = first layer, L hidden layers, final LINEAR with omega / scale taken from the
+        # descriptor: a net that HipINR.forward runs layer by layer is a different function here
+        if getattr(model, "_layerwise", False):
+            raise NotImplementedError("FusedTrainer needs outermost_linear=True: this net ends in an activation layer "
+                                      "(modules/siren.py:81-84, gauss.py:63-66, relu.py:116-119) and runs layer by layer; "
+                                      "train it through model(coords) + torch.optim")
+        if any(getattr(m, "trainable", False) for m in model.net):
+            raise NotImplementedError("FusedTrainer keeps omega_0 / scale_0 fixed (they are not in its flat parameter "
+                                      "buffer); a net with trainable=True layers (modules/wire.py:80-81) trains through "
+                                      "model(coords) + torch.optim")
         p0 = next(model.parameters())
         if not p0.is_cuda:
             raise _lib.WireHipError("FusedTrainer needs the model on an MI355X ('cuda')")
