@@ -131,8 +131,6 @@ int main(int argc, char** argv) {
       {"x3h gabor_bwd recompute", 3, EPI_GABOR_BWD, 1, 0}, {"x2h gabor_bwd recompute (LDS)", 2, EPI_GABOR_BWD, 1, 0},
       {"x2h gabor_bwd recompute (regs)", 2, EPI_GABOR_BWD, 1, 1},
       {"x2h gabor_fwd no out (LDS)", 2, EPI_GABOR_FWD, 2, 0}, {"x2h gabor_fwd no out (regs)", 2, EPI_GABOR_FWD, 2, 1},
-      {"x2h store (regs + L2 prefetch)", 2, EPI_STORE, 0, 2}, {"x2h gabor_fwd (regs + prefetch)", 2, EPI_GABOR_FWD, 0, 2},
-      {"x2h gabor_bwd rec (regs + prefetch)", 2, EPI_GABOR_BWD, 1, 2}, {"x2h fwd no out (regs + prefetch)", 2, EPI_GABOR_FWD, 2, 2},
       // ablation (results wrong): every row of A is row 0 -> all A loads hit the caches
       {"x2h store (LDS), A cached [abl]", 2, EPI_STORE, 0, 10}, {"x2h store (regs), A cached [abl]", 2, EPI_STORE, 0, 11},
   };

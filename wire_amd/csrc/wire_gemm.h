@@ -120,6 +120,7 @@ hipError_t launch_gemmx2h_nt(hipStream_t s, int epi, const float* A, int lda, co
                              int Kd, const GemmEpiParams& ep);
 int gemmx2h_tune_set(const char* key, int value);
 bool gemmx2_tn_applies(int Pm, int Pn);
+int gemmx2_tn_splits(int64_t n, int Pm, int Pn, int max_splits);
 hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n, int Pm,
                             int Pn, int splits, float* slab, float* bslab, const unsigned* amax_g,
                             const unsigned* amax_z);

@@ -54,9 +54,6 @@ typedef unsigned x2u32x2 __attribute__((ext_vector_type(2)));
 #define X2_ABYTES (4 * X2_AWAVE)
 #define X2_BPLANE (X2_TBN * 64)        // 128 columns x 32 k fp16
 #define X2_BSTAGE (2 * X2_BPLANE)      // planes h, l
-#ifndef X2_PFD
-#define X2_PFD 3                       // AMODE 2: stages of L2 prefetch distance
-#endif
 
 WIRE_DEVINL unsigned x2_cvt_pk(float a, float b) {
   const f32x2 v = {a, b};
@@ -204,19 +201,6 @@ __global__ __launch_bounds__(256, 2) void gemmx2h_nt_kernel(const float* __restr
       araw[rb][1] = *reinterpret_cast<const f32x4*>(ab + g_off[rb] + 16);
     }
   };
-  // AMODE 2 = AMODE 1 + an L2 prefetch: a stage's 32 k of a row are exactly one 128-byte line, so one dword per lane
-  // (lane = row of the wave's 64) touches every line of stage kt + X2_PFD; it lands in a scratch LDS word via LDS-DMA (no
-  // register to clobber) and is the youngest memory operation of the stage, which the end-of-stage wait leaves in flight
-  unsigned pf_off;
-  {
-    int row = m_base + wave * 64 + lane;
-    row = row < M ? row : M - 1;
-    pf_off = (unsigned)(row - m_base) * (unsigned)lda * 4u;
-  }
-  auto prefetch = [&](int kt) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_tile + (size_t)kt * (X2_BK * 4) + pf_off),
-                                     (__attribute__((address_space(3))) void*)(smem + wave * 256), 4, 0, 0);
-  };
   auto issue = [&](int kt, int buf) {
     const char* ab = a_tile + (size_t)kt * (X2_BK * 4);
     if constexpr (AMODE == 0) {
@@ -246,12 +230,7 @@ __global__ __launch_bounds__(256, 2) void gemmx2h_nt_kernel(const float* __restr
   const bool half_tile = Nc - n_base <= 64;
 
   issue(0, 0);
-  if constexpr (AMODE >= 1) aload(0);
-  if constexpr (AMODE == 2) {
-#pragma unroll
-    for (int d = 1; d < X2_PFD; ++d)
-      if (d < nk) prefetch(d);
-  }
+  if constexpr (AMODE == 1) aload(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -280,14 +259,10 @@ __global__ __launch_bounds__(256, 2) void gemmx2h_nt_kernel(const float* __restr
       ah[rb] = __builtin_bit_cast(f16x8, x2u32x4{H[0], H[1], H[2], H[3]});
       al[rb] = __builtin_bit_cast(f16x8, x2u32x4{L[0], L[1], L[2], L[3]});
     }
-    if constexpr (AMODE >= 1) {
+    if constexpr (AMODE == 1) {
       // the raw registers are free again: next stage's rows and weight pieces go out under this stage's MFMAs
       __builtin_amdgcn_sched_barrier(0);
       if (kt + 1 < nk) { issue(kt + 1, buf ^ 1); aload(kt + 1); }
-      if constexpr (AMODE == 2) {
-        __builtin_amdgcn_sched_barrier(0);
-        prefetch(kt + X2_PFD < nk ? kt + X2_PFD : nk - 1);
-      }
       __builtin_amdgcn_sched_barrier(0);
     }
     const unsigned char* S = smem + b_rd + buf * X2_BSTAGE;
@@ -312,8 +287,7 @@ __global__ __launch_bounds__(256, 2) void gemmx2h_nt_kernel(const float* __restr
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (AMODE == 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     buf ^= 1;
@@ -325,9 +299,14 @@ static int x2_env(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
 }
-static int g_x2_amode = x2_env("WIRE_X2_AMODE", 0);
+// A/B in one process and on one box (profiles/r03_gemm_x2_nt_tn_ab.txt, N = 262 144, K = 256 complex): A through registers
+// 0.452 / 0.539 / 0.559 ms (store / Gabor forward / data gradient) against 0.470 / 0.556 / 0.563 through LDS.  Measured
+// and dropped (profiles/r03_gemm_x2_prefetch_ablation.txt): an L2 prefetch of the rows three stages ahead (+ 0.02 ms: the
+// cost of the HBM reads is not their latency -- with every A row served from cache the store form takes 0.347 ms, i.e. the
+// 0.54 GB of A cost 0.105 ms, what they cost at 5 TB/s beside a matrix pipe that shares the chip's power budget).
+static int g_x2_amode = x2_env("WIRE_X2_AMODE", 1);
 int gemmx2h_tune_set(const char* key, int value) {
-  if (!strcmp(key, "x2_amode") && value >= 0 && value <= 2) { g_x2_amode = value; return 0; }
+  if (!strcmp(key, "x2_amode") && (value == 0 || value == 1)) { g_x2_amode = value; return 0; }
   return -1;
 }
 
@@ -337,10 +316,7 @@ static hipError_t launchx2h_t(hipStream_t s, const float* A, int lda, const unsi
   const int tiles_m = (int)((M + X2_TBM - 1) / X2_TBM);
   const int tiles_n = (Nc + X2_TBN - 1) / X2_TBN;
   const int tiles_m_pad = (tiles_m + 7) & ~7;
-  if (g_x2_amode == 2)
-    hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 2>), dim3((unsigned)(tiles_m_pad * tiles_n)), dim3(256), 0, s, A, lda, Bx2,
-                       (int)M, Nc, Kd, tiles_m, tiles_n, ep);
-  else if (g_x2_amode == 1)
+  if (g_x2_amode == 1)
     hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 1>), dim3((unsigned)(tiles_m_pad * tiles_n)), dim3(256), 0, s, A, lda, Bx2,
                        (int)M, Nc, Kd, tiles_m, tiles_n, ep);
   else
@@ -378,44 +354,58 @@ hipError_t launch_gemmx2h_nt(hipStream_t s, int epi, const float* A, int lda, co
 }
 
 // ---------------------------------------------------------------------------
-// TN GEMM (weight gradient): slab[s] = G[rows_s]^T Z[rows_s], 256 x 256 features per workgroup of 8 waves -- the
-// 2 x fp16 edition of gemmx3_tn16_kernel (wire_gemmx3.hip), same structure:
+// TN GEMM (weight gradient): slab[s] = G[rows_s]^T Z[rows_s] -- the 2 x fp16 edition of gemmx3_tn16_kernel
+// (wire_gemmx3.hip), same structure, with the workgroup shape a template parameter so that the reference's own widths
+// tile without waste:
+//     WM x WN waves, each 64 features of G x 128 features of Z  ->  tile (64 WM) x (128 WN)
+//     (4, 2): 256 x 256, 8 waves  -- padded widths that are multiples of 256 (K = 256: 512; the 256-feature real nets)
+//     (6, 1): 384 x 128, 6 waves  -- hidden_features = 256 through the reference's API: K = 181, P = 384
+//     (7, 1): 448 x 128, 7 waves  -- the occupancy net as written (3 x 300 -> K = 212, P = 448; its last Z tile is half)
+//     (3, 1): 192 x 128           -- config 1 (2 x 128 -> K = 90, P = 192);  (5, 1): 320 x 128
 //  * the loader splits every fp32 value of a stage once (6 vector ops per 2 values) and stores two fp16 planes per
 //    operand in the [16-feature block][row slot][32 bytes] layout whose transposed fragment reads (ds_read_b64_tr_b16)
-//    and loader stores are 256-byte runs per half wave;
+//    and loader stores are 256-byte runs per half wave; its work units (a pair of feature blocks x 8 row slots) are dealt
+//    round-robin to the waves, the unit -> (block pair, pass) map is wave-uniform and folds into scalar address parts;
 //  * stages of 32 rows: the h h product takes the 32 rows of a stage in ONE 16 x 16 x 32 MFMA (rows 8 g .. 8 g + 7 in
 //    lane group g); the two small products ride together as plane PAIRS in the two k halves of an instruction, once per
 //    16 rows:  Z (h | l) x G (l | h) -> h l + l h.  Three MFMAs per 16 x 16 block and 32 rows (six in the 3 x bf16 kernel).
 //    Row slot of row r: (r & 3) | ((r >> 3) & 3) << 2 | ((r >> 2) & 1) << 4 -- every fragment address is the lane's base
 //    plus an immediate (+ 512: rows + 4; + 256: rows + 16; + 1024: next feature block);
-//  * 2 x 64 KB stage buffers, one workgroup per CU; waves 0-3 / 4-7 (the two waves of each SIMD) half a stage apart;
+//  * two stage buffers of (64 WM + 128 WN) x 128 bytes (64 KB at (4, 2) and (6, 1)), one workgroup per CU; waves >= 4 (SIMD
+//    partners of waves 0-3) run half a stage apart;
 //  * G and Z carry their own power-of-two scales (maximum slots of their producers); the slabs are unscaled on the way out.
 // ---------------------------------------------------------------------------
 typedef short x2s16x4 __attribute__((ext_vector_type(4)));
 #define X2T_TK 32
-#define X2T_PLANE (X2T_TK * 512)                // bytes of one 256-feature fp16 plane of a stage
-#define X2T_STAGE (4 * X2T_PLANE)               // G h, l then Z h, l
 
 WIRE_DEVINL x2s16x4 x2_lds_tr16(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (x2s16x4 __attribute__((address_space(3)))*)(const_cast<unsigned char*>(p)));
 }
 
-__global__ __launch_bounds__(512, 2) void gemmx2_tn16_kernel(
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
     const float* __restrict__ G, int ldg, const float* __restrict__ Z, int ldz, long long n, int Pm, int Pn,
     int tiles_n, int nsplit, long long chunk, float* __restrict__ slab, float* __restrict__ bslab, int tiles,
     const unsigned* __restrict__ amax_g, const unsigned* __restrict__ amax_z) {
+  constexpr int NW = WM * WN;                       // waves
+  constexpr int TM = 64 * WM, TN = 128 * WN;        // tile: features of G x features of Z
+  constexpr int GPLANE = X2T_TK * TM * 2, ZPLANE = X2T_TK * TN * 2;   // bytes of one fp16 plane of a stage
+  constexpr int STAGE = 2 * GPLANE + 2 * ZPLANE;    // G h, G l, Z h, Z l
+  constexpr int UG = 8 * WM, UZ = 16 * WN;          // loader unit pairs (2 feature blocks x 8 row slots x 4 quads) per stage
+  constexpr int IG = (UG + NW - 1) / NW, IZ = (UZ + NW - 1) / NW;     // ... per wave
+  constexpr int PG = TM / 32, PZ = TN / 32;         // feature-block pairs per operand
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wave_m = wave >> 1, wave_n = wave & 1;     // 64 features of G x 128 features of Z per wave
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / WN, wave_n = wave % WN;
   const int bb = blockIdx.x;
   const int xcd = bb & 7, idx = bb >> 3;
   const int tile = idx % tiles;
   const int split = (idx / tiles) * 8 + xcd;
   if (split >= nsplit) return;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
-  const int m_base = tm * 256, n_base = tn * 256;
+  const int m_base = tm * TM, n_base = tn * TN;
   const long long row0 = (long long)split * chunk;
   long long row1 = row0 + chunk;
   if (row1 > n) row1 = n;
@@ -425,84 +415,107 @@ __global__ __launch_bounds__(512, 2) void gemmx2_tn16_kernel(
   wire_x2_scales(wire_amax_read(amax_g, lane), s_g, inv_g);
   wire_x2_scales(wire_amax_read(amax_z, lane), s_z, inv_z);
 
-  // loader: wave w owns feature blocks 2w, 2w + 1 of both operands; a lane = (block half, row slot 0-7, quad p);
-  // pass t = 0..3 writes slots 8 t + (0-7), i.e. rows {0-3, 8-11}, {16-19, 24-27}, {4-7, 12-15}, {20-23, 28-31}
-  const int l_fb = 2 * wave + (lane >> 5), l_rs = (lane >> 2) & 7, l_p = lane & 3;
-  const int l_feat = 16 * l_fb + 4 * l_p;
-  const int l_st = l_fb * 1024 + l_rs * 32 + l_p * 8;   // + 256 per pass
-  // row of pass t = l_row0 + {0, 16, 4, 20}: the pass offsets are wave-uniform and fold into the scalar base
+  // loader lane = (block of the pair, row slot 0-7, feature quad); unit pair u = (block pair u % P, pass u / P); pass t
+  // writes slots 8 t + (0-7), i.e. rows l_row0 + {0, 16, 4, 20}
+  const int l_hb = lane >> 5, l_rs = (lane >> 2) & 7, l_p = lane & 3;
   const int l_row0 = (l_rs & 3) + 8 * (l_rs >> 2);
-  constexpr int pass_row[4] = {0, 16, 4, 20};
+  auto pass_row = [](const int t) { return 16 * (t & 1) + 4 * (t >> 1); };   // 0, 16, 4, 20
+  const int l_feat = 16 * l_hb + 4 * l_p;                 // + 32 (block pair)
+  const int l_st = l_hb * 1024 + l_rs * 32 + l_p * 8;     // + 2048 (block pair) + 256 (pass)
   const bool do_bias = (bslab != nullptr) && (tn == 0);
+  // a Z tile that sticks out of the row (P = 448: the fourth 128-feature tile has 64): its loads stay inside the row
+  const bool z_edge = n_base + TN > Pn;
 
   f32x4 acc[4][8];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  // bias sums: unit pair u = wave + NW i has block pair u % PG = (wave + NW (i % NB)) % PG with NB = PG / NW: one
+  // running sum per distinct block pair of this wave (1 at (4, 2), 2 at (WM, 1)), all passes of a pair added up
+  static_assert(PG % NW == 0, "the block pairs of G must deal out evenly to the waves");
+  constexpr int NB = PG / NW;
+  f32x4 bsum[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) bsum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nrows = (int)(row1 - row0);
   const int nk = (nrows + X2T_TK - 1) / X2T_TK;
   const int nk_full = nrows / X2T_TK;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  struct Staged { f32x4 g[4], z[4]; };
+  struct Staged { f32x4 g[IG], z[IZ]; };
   Staged st;
   const unsigned g_off = (unsigned)l_row0 * (unsigned)ldg + (unsigned)(m_base + l_feat);
   const unsigned z_off = (unsigned)l_row0 * (unsigned)ldz + (unsigned)(n_base + l_feat);
   const float* const g_base = G + (size_t)row0 * ldg;
   const float* const z_base = Z + (size_t)row0 * ldz;
-  auto gload = [&](Staged& R, int kt) {
-    int ks = kt < nk_full ? kt : nk_full - 1;
+  // tail = true: the ragged last stage, rows >= nrows read as zero
+  auto gload = [&](Staged& R, int kt, const bool tail) {
+    int ks = tail ? nk_full : (kt < nk_full ? kt : nk_full - 1);
     ks = ks < 0 ? 0 : ks;
     const float* gb = g_base + (size_t)ks * (X2T_TK * (size_t)ldg);
     const float* zb = z_base + (size_t)ks * (X2T_TK * (size_t)ldz);
+    const int rbase = ks * X2T_TK + l_row0;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) R.g[t] = *reinterpret_cast<const f32x4*>(gb + (size_t)pass_row[t] * ldg + g_off);
+    for (int i = 0; i < IG; ++i) {
+      const int u = wave + NW * i;                          // wave-uniform
+      if (UG % NW == 0 || u < UG) {
+        const int fp = u % PG, t = u / PG;
+        const bool ok = !tail || rbase + pass_row(t) < nrows;
+        R.g[i] = ok ? *reinterpret_cast<const f32x4*>(gb + (size_t)pass_row(t) * ldg + 32 * fp + g_off) : zero4;
+      }
+    }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) R.z[t] = *reinterpret_cast<const f32x4*>(zb + (size_t)pass_row[t] * ldz + z_off);
-  };
-  auto gload_tail = [&](Staged& R) {
-    const int rb = nk_full * X2T_TK;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int row = rb + l_row0 + pass_row[t];
-      R.g[t] = row < nrows ? *reinterpret_cast<const f32x4*>(g_base + (size_t)row * ldg + m_base + l_feat) : zero4;
-      R.z[t] = row < nrows ? *reinterpret_cast<const f32x4*>(z_base + (size_t)row * ldz + n_base + l_feat) : zero4;
+    for (int i = 0; i < IZ; ++i) {
+      const int u = wave + NW * i;
+      if (UZ % NW == 0 || u < UZ) {
+        const int fp = u % PZ, t = u / PZ;
+        bool ok = !tail || rbase + pass_row(t) < nrows;
+        if (z_edge) ok = ok && (n_base + 32 * fp + l_feat < Pn);
+        R.z[i] = ok ? *reinterpret_cast<const f32x4*>(zb + (size_t)pass_row(t) * ldz + 32 * fp + z_off) : zero4;
+      }
     }
   };
   auto lstore = [&](const Staged& R, int buf) {
-    unsigned char* S = smem_t + buf * X2T_STAGE + l_st;
+    unsigned char* S = smem_t + buf * STAGE + l_st;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const f32x4 gv = R.g[t];
-      unsigned h0, l0, h1, l1;
-      x2_split2(gv[0], gv[1], s_g, h0, l0);
-      x2_split2(gv[2], gv[3], s_g, h1, l1);
-      unsigned char* d = S + t * 256;
-      *reinterpret_cast<x2u32x2*>(d) = x2u32x2{h0, h1};
-      *reinterpret_cast<x2u32x2*>(d + X2T_PLANE) = x2u32x2{l0, l1};
-      if (do_bias) { bsum[0] += gv[0]; bsum[1] += gv[1]; bsum[2] += gv[2]; bsum[3] += gv[3]; }
+    for (int i = 0; i < IG; ++i) {
+      const int u = wave + NW * i;
+      if (UG % NW == 0 || u < UG) {
+        const int fp = u % PG, t = u / PG;
+        const f32x4 gv = R.g[i];
+        unsigned h0, l0, h1, l1;
+        x2_split2(gv[0], gv[1], s_g, h0, l0);
+        x2_split2(gv[2], gv[3], s_g, h1, l1);
+        unsigned char* d = S + fp * 2048 + t * 256;
+        *reinterpret_cast<x2u32x2*>(d) = x2u32x2{h0, h1};
+        *reinterpret_cast<x2u32x2*>(d + GPLANE) = x2u32x2{l0, l1};
+        if (do_bias) { bsum[i % NB][0] += gv[0]; bsum[i % NB][1] += gv[1]; bsum[i % NB][2] += gv[2]; bsum[i % NB][3] += gv[3]; }
+      }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const f32x4 zv = R.z[t];
-      unsigned h0, l0, h1, l1;
-      x2_split2(zv[0], zv[1], s_z, h0, l0);
-      x2_split2(zv[2], zv[3], s_z, h1, l1);
-      unsigned char* d = S + 2 * X2T_PLANE + t * 256;
-      *reinterpret_cast<x2u32x2*>(d) = x2u32x2{h0, h1};
-      *reinterpret_cast<x2u32x2*>(d + X2T_PLANE) = x2u32x2{l0, l1};
+    for (int i = 0; i < IZ; ++i) {
+      const int u = wave + NW * i;
+      if (UZ % NW == 0 || u < UZ) {
+        const int fp = u % PZ, t = u / PZ;
+        const f32x4 zv = R.z[i];
+        unsigned h0, l0, h1, l1;
+        x2_split2(zv[0], zv[1], s_z, h0, l0);
+        x2_split2(zv[2], zv[3], s_z, h1, l1);
+        unsigned char* d = S + 2 * GPLANE + fp * 2048 + t * 256;
+        *reinterpret_cast<x2u32x2*>(d) = x2u32x2{h0, h1};
+        *reinterpret_cast<x2u32x2*>(d + ZPLANE) = x2u32x2{l0, l1};
+      }
     }
   };
 
   // fragment reads (plane order in LDS: G h, G l, Z h, Z l)
   const int hi = lane >> 5;
   const int g_hh = lane * 8 + wave_m * (4 * 1024);
-  const int g_pr = (lane & 31) * 8 + (hi ? 0 : 1) * X2T_PLANE + wave_m * (4 * 1024);                    // G (l | h)
-  const int z_hh = 2 * X2T_PLANE + lane * 8 + wave_n * (8 * 1024);
-  const int z_pr = 2 * X2T_PLANE + (lane & 31) * 8 + (hi ? 1 : 0) * X2T_PLANE + wave_n * (8 * 1024);   // Z (h | l)
+  const int g_pr = (lane & 31) * 8 + (hi ? 0 : 1) * GPLANE + wave_m * (4 * 1024);                    // G (l | h)
+  const int z_hh = 2 * GPLANE + lane * 8 + wave_n * (8 * 1024);
+  const int z_pr = 2 * GPLANE + (lane & 31) * 8 + (hi ? 1 : 0) * ZPLANE + wave_n * (8 * 1024);      // Z (h | l)
 
   auto frag = [&](const unsigned char* p) {
     const x2s16x4 a = x2_lds_tr16(p), b = x2_lds_tr16(p + 512);
@@ -510,9 +523,9 @@ __global__ __launch_bounds__(512, 2) void gemmx2_tn16_kernel(
   };
 
   // two passes over the 8 Z blocks, so that at most 40 fragment registers are live beside the 128 accumulator and the
-  // 32 staging registers: the pair products (G pair fragments of the 4 blocks held), then h h (G h fragments held)
+  // staging registers: the pair products (G pair fragments of the 4 blocks held), then h h (G h fragments held)
   auto mfma_block = [&](const int buf) {
-    const unsigned char* S = smem_t + buf * X2T_STAGE;
+    const unsigned char* S = smem_t + buf * STAGE;
     {
       f16x8 gp0[4], gp1[4];
 #pragma unroll
@@ -543,12 +556,14 @@ __global__ __launch_bounds__(512, 2) void gemmx2_tn16_kernel(
       }
     }
   };
+  // stage s of the split into the staging registers: a full stage, the ragged tail, or nothing
   auto load_any = [&](const int sidx) {
-    if (sidx < nk_full) gload(st, sidx);
-    else if (sidx < nk) gload_tail(st);
+    if (sidx < nk_full) gload(st, sidx, false);
+    else if (sidx < nk) gload(st, sidx, true);
   };
   // late (waves 0-3): loads of stage kt + 1 | MFMAs of stage kt | split + store stage kt + 1
-  // early (waves 4-7): split + store stage kt + 1 (loaded a stage ago) | loads of stage kt + 2 | MFMAs of stage kt
+  // early (waves >= 4): split + store stage kt + 1 (loaded a stage ago) | loads of stage kt + 2 | MFMAs of stage kt
+  // Both write buffer (kt + 1) & 1 during stage kt and read buffer kt & 1: the buffer protocol is the same.
   const bool early = wave >= 4;
   load_any(0);
   lstore(st, 0);
@@ -558,13 +573,13 @@ __global__ __launch_bounds__(512, 2) void gemmx2_tn16_kernel(
   auto stage = [&](const int kt, const bool fast) {
     const int buf = kt & 1;
     if (!early) {
-      if (fast) gload(st, kt + 1); else load_any(kt + 1);
+      if (fast) gload(st, kt + 1, false); else load_any(kt + 1);
       __builtin_amdgcn_sched_barrier(0);
       mfma_block(buf);
       if (fast || kt + 1 < nk) lstore(st, buf ^ 1);
     } else {
       if (fast || kt + 1 < nk) lstore(st, buf ^ 1);
-      if (fast) gload(st, kt + 2); else load_any(kt + 2);
+      if (fast) gload(st, kt + 2, false); else load_any(kt + 2);
       __builtin_amdgcn_sched_barrier(0);
       mfma_block(buf);
     }
@@ -575,15 +590,19 @@ __global__ __launch_bounds__(512, 2) void gemmx2_tn16_kernel(
   for (; kt < nk; ++kt) stage(kt, false);
 
   if (do_bias) {
-    // the 8 row-slot lanes of a feature quad: sum through LDS (all fragment reads are done)
-    float* red = reinterpret_cast<float*>(smem_t);
-    *reinterpret_cast<f32x4*>(&red[l_rs * 256 + l_feat]) = bsum;
+    // the 8 row-slot lanes of a feature quad and the 4 passes of a block pair: sum through LDS (all fragment reads are done)
+    float* red = reinterpret_cast<float*>(smem_t);       // [8 row slots][TM features]
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int fp = (wave + NW * i) % PG;
+      *reinterpret_cast<f32x4*>(&red[l_rs * TM + 32 * fp + l_feat]) = bsum[i];
+    }
     __syncthreads();
-    if (tid < 256) {
+    for (int f = tid; f < TM; f += 64 * NW) {
       float v = 0.f;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v += red[r * 256 + tid];
-      bslab[(size_t)split * Pm + m_base + tid] = v;
+      for (int r = 0; r < 8; ++r) v += red[r * TM + f];
+      bslab[(size_t)split * Pm + m_base + f] = v;
     }
   }
   // accumulator block (i, j): lane -> G feature 16 i + (lane & 15), Z features 16 j + 4 (lane >> 4) + q; blocks j, j + 1
@@ -601,21 +620,67 @@ __global__ __launch_bounds__(512, 2) void gemmx2_tn16_kernel(
 #pragma unroll
       for (int q = 0; q < 4; ++q) { xp[q] *= inv; yp[q] *= inv; }
       const int col = n_base + wave_n * 128 + 32 * jp + cq;
-      *reinterpret_cast<f32x4*>(out + (size_t)m * Pn + col) = xp;
-      *reinterpret_cast<f32x4*>(out + (size_t)(m + 8) * Pn + col) = yp;
+      if (col < Pn) {                                    // (an edge Z tile: its upper 32-column spans do not exist)
+        *reinterpret_cast<f32x4*>(out + (size_t)m * Pn + col) = xp;
+        *reinterpret_cast<f32x4*>(out + (size_t)(m + 8) * Pn + col) = yp;
+      }
     }
   }
 }
 
-bool gemmx2_tn_applies(int Pm, int Pn) { return Pm % 256 == 0 && Pn % 256 == 0; }
+// workgroup shape for a weight gradient of Pm x Pn padded features (multiples of 64): 0 = none (3 x bf16 kernels)
+static int x2_tn_shape(int Pm, int Pn) {
+  if ((Pm & 63) || (Pn & 63) || Pm < 64 || Pn < 64) return 0;
+  if (Pm % 256 == 0 && Pn % 256 == 0) return 42;
+  if (Pm == 384) return 61;
+  if (Pm == 448) return 71;
+  if (Pm == 320) return 51;
+  if (Pm == 192) return 31;
+  return 0;
+}
+bool gemmx2_tn_applies(int Pm, int Pn) { return x2_tn_shape(Pm, Pn) != 0; }
+// row splits that fill the 256 CUs with one workgroup each
+int gemmx2_tn_splits(int64_t n, int Pm, int Pn, int max_splits) {
+  const int shp = x2_tn_shape(Pm, Pn);
+  if (!shp) return 0;
+  const int TMf = 64 * (shp / 10), TNf = 128 * (shp % 10);
+  const int tiles = (Pm / TMf) * ((Pn + TNf - 1) / TNf);
+  int s = tiles >= 256 ? 1 : 256 / tiles;
+  int64_t by_rows = (n + 255) / 256;                     // at least 256 rows per split
+  if (by_rows < 1) by_rows = 1;
+  if (s > by_rows) s = (int)by_rows;
+  if (s > max_splits) s = max_splits;
+  if (s < 1) s = 1;
+  if (n < 1) return s;
+  long long chunk = (n + s - 1) / s;
+  chunk = (chunk + 2 * X2T_TK - 1) / (2 * X2T_TK) * (2 * X2T_TK);
+  s = (int)((n + chunk - 1) / chunk);
+  return s < 1 ? 1 : s;
+}
 
-// same split / chunk conventions as launch_gemmx3_tn (wire_gemmx3.hip): `splits` from gemmx3_tn_splits
+template <int WM, int WN>
+static hipError_t launch_x2_tn_t(hipStream_t s, dim3 grid, const float* G, int ldg, const float* Z, int ldz, int64_t n,
+                                 int Pm, int Pn, int tiles_n, int used, long long chunk, float* slab, float* bslab,
+                                 int tiles, const unsigned* amax_g, const unsigned* amax_z) {
+  constexpr int STAGE = X2T_TK * (64 * WM + 128 * WN) * 4;
+  // > 64 KB of dynamic LDS needs the opt-in; per launch (a host-side call of about a microsecond), because the attribute
+  // belongs to the current device's copy of the function and a process may drive more than one
+  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemmx2_tn16_kernel<WM, WN>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+  if (attr != hipSuccess) return attr;
+  hipLaunchKernelGGL((gemmx2_tn16_kernel<WM, WN>), grid, dim3(64 * WM * WN), 2 * STAGE, s, G, ldg, Z, ldz, (long long)n,
+                     Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles, amax_g, amax_z);
+  return hipGetLastError();
+}
+
+// `splits` from gemmx2_tn_splits; slabs [splits][Pm][Pn] (+ bslab [splits][Pm]) as launch_gemmx3_tn writes them
 hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n, int Pm,
                             int Pn, int splits, float* slab, float* bslab, const unsigned* amax_g,
                             const unsigned* amax_z) {
-  if (!gemmx2_tn_applies(Pm, Pn) || (ldg & 3) || (ldz & 3) || splits < 1 || n < 1 || !amax_g || !amax_z)
-    return hipErrorInvalidValue;
-  const int tiles_m = Pm / 256, tiles_n = Pn / 256;
+  const int shp = x2_tn_shape(Pm, Pn);
+  if (!shp || (ldg & 3) || (ldz & 3) || splits < 1 || n < 1 || !amax_g || !amax_z) return hipErrorInvalidValue;
+  const int TMf = 64 * (shp / 10), TNf = 128 * (shp % 10);
+  const int tiles_m = Pm / TMf, tiles_n = (Pn + TNf - 1) / TNf;
   long long chunk = (n + splits - 1) / splits;
   chunk = (chunk + 2 * X2T_TK - 1) / (2 * X2T_TK) * (2 * X2T_TK);
   const int used = (int)((n + chunk - 1) / chunk);
@@ -629,10 +694,14 @@ hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float*
       if (e != hipSuccess) return e;
     }
   }
-  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemmx2_tn16_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * X2T_STAGE);
-  if (attr != hipSuccess) return attr;
-  hipLaunchKernelGGL(gemmx2_tn16_kernel, grid, dim3(512), 2 * X2T_STAGE, s, G, ldg, Z, ldz, (long long)n, Pm, Pn,
-                     tiles_n, used, chunk, slab, bslab, tiles_m * tiles_n, amax_g, amax_z);
-  return hipGetLastError();
+#define X2_TN_ARGS s, grid, G, ldg, Z, ldz, n, Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles_m * tiles_n, amax_g, amax_z
+  switch (shp) {
+    case 42: return launch_x2_tn_t<4, 2>(X2_TN_ARGS);
+    case 61: return launch_x2_tn_t<6, 1>(X2_TN_ARGS);
+    case 71: return launch_x2_tn_t<7, 1>(X2_TN_ARGS);
+    case 51: return launch_x2_tn_t<5, 1>(X2_TN_ARGS);
+    case 31: return launch_x2_tn_t<3, 1>(X2_TN_ARGS);
+    default: return hipErrorInvalidValue;
+  }
+#undef X2_TN_ARGS
 }
