@@ -25,12 +25,15 @@ The JSON line also carries
                  events on the launch stream (inside the timed region, on every
                  5th step: see prof_step); achieved = algorithmic flops (8
                  flop per complex MAC) / average launch duration.
-                 Default path (split-bf16, wire_gemmx3.hip): every fp32 product
-                 is 6 bf16 MFMA products, so the ceiling of the algorithm is
-                 the dense bf16 MFMA peak / 6 = 416.7 fp32-equivalent TFLOP/s;
-                 with WIRE_SPLIT_BF16=0 (fp32-MFMA kernels) it is 157.3.
-                 mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) of that kernel
-                 from the committed PMC summary (profiles/pmc_traffic.json; rocprofv3 --pmc in its own passes).
+                 Default path (2 x fp16 split, wire_gemmx2h.hip): every fp32 product
+                 is 3 f16 MFMA products, so the ceiling of the algorithm is
+                 the dense f16 MFMA peak / 3 = 833.3 fp32-equivalent TFLOP/s
+                 (WIRE_SPLIT_F16=0: the 3 x bf16 split of round 2, 6 products, 416.7;
+                 WIRE_SPLIT_BF16=0: fp32-MFMA kernels, 157.3).
+                 traffic / mfma_busy = (2 FETCH_SIZE + WRITE_SIZE) KiB and SQ_VALU_MFMA_BUSY_CYCLES /
+                 (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) of that kernel from profiles/pmc_traffic.json, which
+                 tools/pmc_traffic.py writes from rocprofv3 --pmc passes (their own runs) together with the hash
+                 of the library sources; null when this tree's sources differ.
   cpu_baseline : the oracle's eager-PyTorch restatement of the reference's CPU
                  path (kind "port"), timed on this host's cores on a bounded
                  sample of the same workload.
@@ -52,7 +55,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 256 flop/clk x 2.4 GHz
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (16x the fp32 MFMA rate)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / f16 MFMA (16x the fp32 MFMA rate)
 PROF_EVERY = 5                  # per-launch HIP events on every 5th step of a timed region (see prof_step)
 HIDDEN_FEATURES = 363           # -> K = int(363/sqrt(2)) = 256 complex features
 L, D, O = 4, 2, 3
@@ -73,6 +76,30 @@ def spawn_ranks(n: int) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
+
+
+def csrc_sha() -> str:
+    """Hash of the library's sources (wire_amd/csrc, include/): ties profiles/pmc_traffic.json to the code it profiled."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(ROOT, "include", "wire_hip.h")]
+    d = os.path.join(ROOT, "wire_amd", "csrc")
+    files += sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hip", ".h")) or f == "Makefile")
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def family(lib):
+    """(split products per fp32 product, dtype string, roofline peak in fp32-equivalent TFLOP/s) of the GEMM family the
+    flags select for large batches: 3 = 2 x fp16 split (wire_gemmx2h.hip), 6 = 3 x bf16 split (wire_gemmx3*.hip),
+    0 = fp32 MFMA."""
+    if lib.wire_tune_get(b"split_bf16") != 1:
+        return 0, "f32", PEAK_FP32_MFMA_TFLOPS
+    if lib.wire_tune_get(b"split_f16") == 1 and lib.wire_tune_get(b"x3_h16") & 3 == 3:
+        return 3, "f32 (2xfp16 split operands with power-of-two scales, f16 MFMA, fp32 accumulate)", PEAK_BF16_MFMA_TFLOPS / 3.0
+    return 6, "f32 (3xbf16 split operands, bf16 MFMA, fp32 accumulate)", PEAK_BF16_MFMA_TFLOPS / 6.0
 
 
 def host_cores() -> int:
@@ -97,7 +124,7 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def cpu_baseline(n_sample: int, iters: int):
+def cpu_baseline(n_sample: int, iters: int, hidden_features: int = HIDDEN_FEATURES):
     """Reference CPU path (eager PyTorch restatement from oracle/) on a bounded sample:
     1 warm-up + `iters` timed fwd + bwd + Adam steps over the first n_sample coordinates of the same workload,
     and the same number of forward-only passes."""
@@ -105,7 +132,7 @@ def cpu_baseline(n_sample: int, iters: int):
     from oracle import torch_ref, wire_oracle as wo
     cores = host_cores()
     torch.set_num_threads(cores)
-    p = torch_ref.init_wire_params(D, HIDDEN_FEATURES, L, O, seed=0)
+    p = torch_ref.init_wire_params(D, hidden_features, L, O, seed=0)
     coords = torch.tensor(wo.image_coords(SIDE, SIDE))[:n_sample][None]
     g = torch.Generator().manual_seed(0)
     target = torch.rand(1, n_sample, O, generator=g)
@@ -122,8 +149,9 @@ def cpu_baseline(n_sample: int, iters: int):
     return {"value": n_sample * iters / dt, "unit": "coord-samples/s", "cores": cores, "kind": "port",
             "cpu_model": cpu_model(), "forward_only_value": n_sample * iters / dtf,
             "sample": f"{iters} timed fwd+bwd+Adam steps (after 1 warm-up) and {iters} forward-only passes over the "
-                      f"first {n_sample} coords of the 512x512 grid, 4x256 complex WIRE, torch {torch.__version__} "
-                      f"CPU eager, {cores} threads (oracle/torch_ref.py)"}
+                      f"first {n_sample} coords of the 512x512 grid, 4x{wo.complex_width(hidden_features)} complex WIRE "
+                      f"(hidden_features={hidden_features}), torch {torch.__version__} CPU eager, {cores} threads "
+                      f"(oracle/torch_ref.py)"}
 
 
 def alg_flops(kind, K, Ln, Din, On):
@@ -182,8 +210,7 @@ def timed_config(dev, lib, kind, side, hf, steps, warmup=2, **kw):
     klass = max(range(3), key=lambda i: ms[i])
     avg_ms = ms[klass] / max(1, cnt[klass])
     gemm_tf = fl[klass] / max(1, cnt[klass]) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-    split = lib.wire_tune_get(b"split_bf16") == 1
-    peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_FP32_MFMA_TFLOPS
+    _, _, peak = family(lib)
     res = {"samples_per_s": n / dt, "ms_per_step": dt * 1e3, "K": K, "coords_per_step": n, "steps": steps,
            "alg_flop_per_sample": F, "whole_step_tflops": n / dt * F / 1e12,
            "whole_step_frac": n / dt * F / 1e12 / peak,
@@ -231,6 +258,34 @@ def extras(dev, lib):
             res["fp32_mfma_family"]["dtype"] = "f32 (v_mfma_f32_32x32x2_f32, 3-multiplication complex product)"
         finally:
             lib.wire_tune_set(b"split_bf16", 1)
+    # the 3 x bf16 split family (round 2's default: 6 bf16 MFMA products per fp32 product) on the headline workload
+    if lib.wire_tune_get(b"split_f16") == 1:
+        lib.wire_tune_set(b"split_f16", 0)
+        try:
+            res["bf16x3_family"] = timed_config(dev, lib, "wire", SIDE, HIDDEN_FEATURES, 8, **wire_kw)
+            res["bf16x3_family"]["dtype"] = "f32 (3xbf16 split operands, bf16 MFMA, fp32 accumulate)"
+        finally:
+            lib.wire_tune_set(b"split_f16", 1)
+    # the reference's literal epoch shuffle, torch.randperm(H*W) per step (wire_image_denoise.py:142), instead of the
+    # position-keyed bijection of the headline: what the shuffle choice is worth
+    torch.manual_seed(0)
+    model = models.get_INR(nonlin="wire", in_features=D, out_features=O, hidden_features=HIDDEN_FEATURES,
+                           hidden_layers=L, **wire_kw).to(dev)
+    g = torch.Generator().manual_seed(0)
+    tr = FusedTrainer(model, (SIDE, SIDE), torch.rand(SIDE * SIDE, O, generator=g), lr=5e-3, niters=2000)
+    for _ in range(2):
+        tr.step(tr.permutation())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        tr.step(tr.permutation())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    res["randperm_shuffle"] = {"samples_per_s": SIDE * SIDE / dt, "ms_per_step": dt * 1e3,
+                               "note": "headline workload with torch.randperm(H*W) per step (prefetched on a side stream) "
+                                       "instead of wire_perm_indices"}
+    del tr, model
+    torch.cuda.empty_cache()
     # BASELINE.json configs[3] and [4] through the same trainer (bounded steps)
     res["cfg4_wire2d_4x256_1024x1024"] = timed_config(dev, lib, "wire2d", 1024, 256, 4, first_omega_0=10.0,
                                                       hidden_omega_0=10.0, scale=10.0)
@@ -344,18 +399,22 @@ def main():
         n_gpu_batch = npts // world
         F = alg_flops("wire", K, L, D, O)               # SURVEY 8(d) algorithmic flop / sample
         value = npts * args.steps / dt
-        split = lib.wire_tune_get(b"split_bf16") == 1
-        if split:
+        nprod, dtype_name, peak = family(lib)
+        split = nprod != 0
+        if nprod == 3:
+            names = ["gemmx2h_nt<gabor_fwd> (layer forward, 2xfp16 split, 16x16x32 f16 MFMA)",
+                     "gemmx2h_nt<gabor_bwd> (data gradient, 2xfp16 split, 16x16x32 f16 MFMA)",
+                     ("gemmx2_tn16 (weight gradient, 2xfp16 split, 16x16x32 f16 MFMA)" if (2 * K + 63) // 64 * 64 in (384, 448)
+                      or (2 * K) % 256 == 0 else "gemmx3_tn (weight gradient, 3xbf16 split)"), "other"]
+        elif split:
             h16 = lib.wire_tune_get(b"x3_h16")
             names = [("gemmx3h_nt<gabor_fwd> (layer forward, 16x16x32 MFMA)" if h16 & 1 else "gemmx3_nt<gabor_fwd> (layer forward)"),
                      ("gemmx3h_nt<gabor_bwd> (data gradient, 16x16x32 MFMA)" if h16 & 2 else "gemmx3_nt<gabor_bwd> (data gradient)"),
                      ("gemmx3_tn16 (weight gradient, 16x16x32 MFMA)" if lib.wire_tune_get(b"x3_tn16") == 1 and (2 * K) % 256 == 0
                       else "gemmx3_tn (weight gradient)"), "other"]
-            peak = PEAK_BF16_MFMA_TFLOPS / 6.0          # 6 bf16 partial products per fp32 product
         else:
             names = ["gemm3m_nt<gabor_fwd> (layer forward)", "gemm3m_nt<gabor_bwd> (data gradient)",
                      "gemm3m_tn (weight gradient)", "other"]
-            peak = PEAK_FP32_MFMA_TFLOPS
         alg_per_launch = 8.0 * K * K * (n_gpu_batch / max(1, args.micro_shards))   # per hidden-layer GEMM
         klass = max(range(3), key=lambda i: ms[i])
         avg_ms = ms[klass] / max(1, cnt[klass])
@@ -364,12 +423,20 @@ def main():
         hbm = None
         mfma_busy = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        pmc_note = "profiles/pmc_traffic.json absent"
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                fam = tj.get("split_bf16", {}) if split else tj.get("fp32_mfma", tj)
+                # written by tools/pmc_traffic.py from the rocprofv3 --pmc passes of tools/profile_round.sh; only valid for the
+                # library sources it profiled and for the default flags
+                default_flags = nprod == 3 and args.hidden_features == HIDDEN_FEATURES
+                if tj.get("csrc_sha") != csrc_sha() or not default_flags:
+                    raise ValueError(f"pmc_traffic.json is for sources {tj.get('csrc_sha')}, this tree is {csrc_sha()} "
+                                     f"(or non-default flags): traffic / mfma_busy not reported")
+                fam = tj.get("traffic", {})
                 traffic = fam.get(str(klass))
-                mfma_busy = (tj.get("mfma_busy", {}).get("split_bf16" if split else "fp32_mfma", {}) or {}).get(str(klass))
+                mfma_busy = tj.get("mfma_busy", {}).get(str(klass))
+                pmc_note = f"rocprofv3 --pmc passes of sources {tj.get('csrc_sha')}: {', '.join(tj.get('kernels', {}).get(str(klass), []))}"
                 # HBM rate of the GEMMs from the PMC byte counts per launch (committed profile) and the launch
                 # times measured in THIS run: evidence of fusion quality, not the bound
                 if all(str(i) in fam and cnt[i] > 0 for i in range(3)) and args.micro_shards == 1 and world == 1:
@@ -378,14 +445,14 @@ def main():
                     hbm = {"gemm_bytes_per_step": gb / max(1, n_prof), "gemm_tb_per_s": gb / (gms * 1e-3) / 1e12,
                            "frac_of_8_tb_per_s": gb / (gms * 1e-3) / 8e12,
                            "source": "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE) x launches / GEMM time of this run"}
-            except Exception:
-                traffic = None
+            except Exception as e:
+                traffic, mfma_busy, hbm, pmc_note = None, None, None, str(e)
         out = {
             "metric": "coord-samples/sec fwd+bwd, 4x256 complex WIRE MLP",
             "value": value, "unit": "coord-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (3xbf16 split operands, bf16 MFMA, fp32 accumulate)" if split else "f32",
+            "dtype": dtype_name,
             "data": "synthetic",
             "config": {"workload": f"512x{512 * world} image fit, WIRE 4 hidden x {K} complex "
                                    f"(hidden_features={args.hidden_features}), D=2 O=3 omega0=20 sigma0=30, "
@@ -394,12 +461,13 @@ def main():
                        "shuffle": args.shuffle, "backend": backend if world > 1 else None},
             "roofline": {"bound": "mfma", "kernel": names[klass], "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                         "mfma_busy": mfma_busy,
+                         "mfma_busy": mfma_busy, "pmc_source": pmc_note,
                          "avg_launch_ms": avg_ms, "launches": int(cnt[klass]),
                          "alg_flops_per_launch": alg_per_launch,
-                         "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per fp32 product; "
-                                       "executed bf16 rate = 6 x achieved") if split else "fp32 MFMA peak",
-                         "executed_mfma_tflops": achieved * (6.0 if split else 0.75),
+                         "peak_note": (f"dense f16 / bf16 MFMA peak 2500 TFLOP/s / {nprod} partial products per fp32 product; "
+                                       f"executed MFMA rate = {nprod} x achieved; against the 3xbf16 family's 416.7 this is "
+                                       f"{achieved / (PEAK_BF16_MFMA_TFLOPS / 6.0):.3f}") if split else "fp32 MFMA peak",
+                         "executed_mfma_tflops": achieved * (float(nprod) if split else 0.75),
                          "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS},
             "whole_step_tflops": value / world * F / 1e12,
             "whole_step_frac_of_fp32_mfma_peak": value / world * F / 1e12 / PEAK_FP32_MFMA_TFLOPS,
@@ -412,7 +480,12 @@ def main():
         if world == 1 and not args.no_extras:
             out["extras"] = extras(dev, lib)
         if world == 1 and not args.no_cpu_baseline:
+            # N = 65 536 and 262 144, 4 x 256 and 4 x 181 complex (bounded: 3 + 1 iterations each)
             out["cpu_baseline"] = cpu_baseline(65536, 3)
+            out["cpu_baseline"]["more"] = {
+                "n262144_k256": cpu_baseline(262144, 2),
+                "n65536_k181_api_hidden_features_256": cpu_baseline(65536, 3, 256),
+                "n262144_k181_api_hidden_features_256": cpu_baseline(262144, 2, 256)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -115,10 +115,11 @@ int wire_mlp_bwd(void* stream, const wire_net_desc* d, const float* packed,
  * model(b_coords) -> rec[b_indices] = pix -> mse -> backward): forward, MSE against
  * target[idx[r]] (or target[first + r] when idx is NULL), loss_out[0] = weight *
  * mean((y - t)^2), optional rec scatter, and every parameter gradient of
- * weight * loss into grads_host (overwritten).  For `wire` with O <= 4 the final
- * linear forward, the loss, its gradient, the final linear backward and the last
- * layer's Gabor gradient are ONE kernel (a single pass over out_L / lin_L); other
- * kinds run wire_mlp_fwd + wire_mse_grad + wire_mlp_bwd internally.
+ * weight * loss into grads_host (overwritten).  For every net kind with at least one
+ * hidden layer and O <= 4 the final linear forward, the loss, its gradient, the final
+ * linear backward and the last layer's activation gradient are ONE kernel (a single pass
+ * over out_L / lin_L, final_fused_kernel); nets without a hidden layer or with O > 4 run
+ * wire_mlp_fwd + wire_mse_grad + wire_mlp_bwd internally.
  * y [n][O] and g_y [n][O] are outputs; partial >= 4096 floats.                 */
 int wire_train_fwd_bwd(void* stream, const wire_net_desc* d, const float* packed,
                        const float* coords, int64_t n, const float* target,
@@ -265,6 +266,15 @@ int wire_c64_to_blocked(void* stream, const void* src, int64_t n, int K, float* 
 int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* dst);
 
 /* ---- tuning knobs ---------------------------------------------------------
+ * "split_f16" (default 1; environment WIRE_SPLIT_F16; needs split_bf16 = 1 and the x3_h16 bits of the net kind): the
+ *     hidden-layer GEMMs of batches of >= 4096 rows run as a TWO-way fp16 split on v_mfma_f32_16x16x32_f16
+ *     (wire_gemmx2h.hip): x s = h + l with s a power of two that maps the operand tensor's max |value| to [2^14, 2^15),
+ *     three partial products per fp32 product (h h + h l + l h), fp32 accumulate -- fp32-accurate (measured rms error
+ *     0.64 - 0.78 x the fp32 MFMA chain's, tools/f16x2_numerics.hip) at half the matrix-core work of the 3 x bf16
+ *     split.  The maxima are tracked on the device by each tensor's producer kernel (64 sharded atomicMax slots inside
+ *     the act / scratch / packed buffers) and read by the consumer kernel: no host round trip.  "x2_amode" (default 1):
+ *     1 = the activation operand goes from global memory straight into fragment registers, 0 = through LDS.
+ *     0 = the 3 x bf16 kernels below for every batch size.
  * "split_bf16" (default 1; environment WIRE_SPLIT_BF16): every GEMM of every net
  *     kind runs on the bf16 matrix cores with each fp32 operand split exactly into
  *     three bf16 terms (6 partial products, fp32 accumulate; fp32-accurate --
@@ -286,12 +296,13 @@ int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* 
  *     first layer's per-tile gradient sums itself instead of storing g_u for a separate reduction pass.
  * "x3_glds" (default 0): 1 / 2 = LDS-DMA 32x32x16 editions of the split-bf16 NT GEMM at M >= 4096
  *     (wire_gemmx3g.hip).  All editions give bit-identical GEMM results.
- * Neither buffer sizes (wire_packed_floats, wire_act_bytes, wire_bwd_scratch_bytes) nor
- * buffer CONTENTS depend on the knobs: wire_pack_params writes the weight image of every
- * family, activations are fp32 blocked rows for all of them, so a knob may change between
- * a forward and its backward.                                                  */
+ * Buffer sizes (wire_packed_floats, wire_act_bytes, wire_bwd_scratch_bytes) and the layout of packed weights do not
+ * depend on the knobs: wire_pack_params writes the weight image of every family, activations are fp32 blocked rows for
+ * all of them.  The knobs must NOT change between a forward and the backward that consumes its activation buffer: the
+ * backward re-derives from them which kernel edition produced the activations (recompute_out: the lean forward form
+ * whose bits it reproduces) and whether the forward filled the max-|value| slots the 2 x fp16 kernels scale by.     */
 int wire_tune_set(const char* key, int value);
-int wire_tune_get(const char* key);   /* "split_bf16" | "complex_3m" | "x3_h16" | "x3_tn16" | "recompute_out" -> value; < 0 = error */
+int wire_tune_get(const char* key);   /* "split_bf16" | "split_f16" | "complex_3m" | "x3_h16" | "x3_tn16" | "recompute_out" -> value; < 0 = error */
 
 /* ---- profiling hooks (bench.py roofline) -------------------------------
  * When enabled, every launch of the hot kernels is bracketed by hipEvents on

@@ -17,7 +17,9 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc2 -- $BENCH > $OUT/pmc2.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc3 -- $BENCH > $OUT/pmc3.log 2>&1
 python3 tools/pmc_summary.py $(find $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 -name "*counter_collection.csv") > gpurun_out/${TAG}_pmc_summary.txt
+# per-class traffic / matrix-pipe busy + the hash of the sources they belong to: what bench.py's roofline.traffic reads
+python3 tools/pmc_traffic.py $(find $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 -name "*counter_collection.csv") > gpurun_out/${TAG}_pmc_traffic.json
 C1=$(find $OUT/pmc1 -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_dispatch_table.py "$C1" gemm > gpurun_out/${TAG}_pmc_dispatch_table.txt
 head -40 gpurun_out/${TAG}_rocprofv3_kernel_stats.csv
-grep -A12 "gemmx3" gpurun_out/${TAG}_pmc_summary.txt | head -80
+grep -A12 "gemmx" gpurun_out/${TAG}_pmc_summary.txt | head -100

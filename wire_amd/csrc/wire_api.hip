@@ -601,9 +601,11 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
       ProfScope ps(s, 3, 0);
       HIPCHK(launch_wgrad3m_reduce(s, Sx + sc.slab, Sx + sc.bslab, S, p.K, p.K, p.Kp, p.Kp, gW, gb));
     } else {
-      const int S = p.x3 ? gemmx3_tn_splits(n, p.Pl, p.P, sc.S) : gemm_tn_splits(n, p.Pl, p.P, sc.S);
+      const bool x2tn = x2 && gemmx2_tn_applies(p.Pl, p.P);
+      const int S = x2tn ? gemmx2_tn_splits(n, p.Pl, p.P, sc.S)
+                         : (p.x3 ? gemmx3_tn_splits(n, p.Pl, p.P, sc.S) : gemm_tn_splits(n, p.Pl, p.P, sc.S));
       { ProfScope ps(s, 2, 2.0 * n * p.Pl * p.P);
-        if (x2 && gemmx2_tn_applies(p.Pl, p.P))
+        if (x2tn)
           HIPCHK(launch_gemmx2_tn(s, gcur, p.Pl, out_l(l - 1), p.P, n, p.Pl, p.P, S, Sx + sc.slab, Sx + sc.bslab,
                                   gamax + l * WIRE_AMAX_SLOTS, amax + (l - 1) * WIRE_AMAX_SLOTS));
         else if (p.x3)

@@ -361,7 +361,7 @@ hipError_t launch_gemmx2h_nt(hipStream_t s, int epi, const float* A, int lda, co
 //     (4, 2): 256 x 256, 8 waves  -- padded widths that are multiples of 256 (K = 256: 512; the 256-feature real nets)
 //     (6, 1): 384 x 128, 6 waves  -- hidden_features = 256 through the reference's API: K = 181, P = 384
 //     (7, 1): 448 x 128, 7 waves  -- the occupancy net as written (3 x 300 -> K = 212, P = 448; its last Z tile is half)
-//     (3, 1): 192 x 128           -- config 1 (2 x 128 -> K = 90, P = 192);  (5, 1): 320 x 128
+//   (other widths -- config 1's K = 90, P = 192 -- keep the 128 x 128 3 x bf16 kernel of wire_gemmx3.hip)
 //  * the loader splits every fp32 value of a stage once (6 vector ops per 2 values) and stores two fp16 planes per
 //    operand in the [16-feature block][row slot][32 bytes] layout whose transposed fragment reads (ds_read_b64_tr_b16)
 //    and loader stores are 256-byte runs per half wave; its work units (a pair of feature blocks x 8 row slots) are dealt
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
   constexpr int PG = TM / 32, PZ = TN / 32;         // feature-block pairs per operand
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, wave = tid >> 6;   // (kept a vector value: as a scalar it drives the allocator over its budget)
   const int wave_m = wave / WN, wave_n = wave % WN;
   const int bb = blockIdx.x;
   const int xcd = bb & 7, idx = bb >> 3;
@@ -431,10 +431,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // bias sums: unit pair u = wave + NW i has block pair u % PG = (wave + NW (i % NB)) % PG with NB = PG / NW: one
-  // running sum per distinct block pair of this wave (1 at (4, 2), 2 at (WM, 1)), all passes of a pair added up
-  static_assert(PG % NW == 0, "the block pairs of G must deal out evenly to the waves");
+  // G units of wave w: block pairs w + NW b, b < NB = PG / NW (1 at (4, 2), 2 at (WM, 1)), each in all 4 passes: unit i =
+  // (block pair w + NW (i % NB), pass i / NB) -- the pass is a compile-time constant, the block pair one scalar.  Z units:
+  // (4, 2): block pair w, pass i, likewise; (WM, 1): 16 units dealt round-robin, u = w + NW i < 16, pair u & 3, pass u >> 2.
+  // Bias sums: one running sum per block pair of this wave, all passes added up.
+  static_assert(PG % NW == 0 && IG == 4 * (PG / NW), "the block pairs of G must deal out evenly to the waves");
+  static_assert(PZ == NW || PZ == 4, "Z units: one block pair per wave, or 4 block pairs dealt round-robin");
   constexpr int NB = PG / NW;
+  constexpr bool ZFIX = (PZ == NW);
   f32x4 bsum[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) bsum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -459,18 +463,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
     const int rbase = ks * X2T_TK + l_row0;
 #pragma unroll
     for (int i = 0; i < IG; ++i) {
-      const int u = wave + NW * i;                          // wave-uniform
-      if (UG % NW == 0 || u < UG) {
-        const int fp = u % PG, t = u / PG;
-        const bool ok = !tail || rbase + pass_row(t) < nrows;
-        R.g[i] = ok ? *reinterpret_cast<const f32x4*>(gb + (size_t)pass_row(t) * ldg + 32 * fp + g_off) : zero4;
-      }
+      const int fp = wave + NW * (i % NB), t = i / NB;
+      const bool ok = !tail || rbase + pass_row(t) < nrows;
+      R.g[i] = ok ? *reinterpret_cast<const f32x4*>(gb + (size_t)pass_row(t) * ldg + 32 * fp + g_off) : zero4;
     }
 #pragma unroll
     for (int i = 0; i < IZ; ++i) {
       const int u = wave + NW * i;
-      if (UZ % NW == 0 || u < UZ) {
-        const int fp = u % PZ, t = u / PZ;
+      if (ZFIX || u < UZ) {
+        const int fp = ZFIX ? wave : (u & 3), t = ZFIX ? i : (u >> 2);
         bool ok = !tail || rbase + pass_row(t) < nrows;
         if (z_edge) ok = ok && (n_base + 32 * fp + l_feat < Pn);
         R.z[i] = ok ? *reinterpret_cast<const f32x4*>(zb + (size_t)pass_row(t) * ldz + 32 * fp + z_off) : zero4;
@@ -481,24 +482,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
     unsigned char* S = smem_t + buf * STAGE + l_st;
 #pragma unroll
     for (int i = 0; i < IG; ++i) {
-      const int u = wave + NW * i;
-      if (UG % NW == 0 || u < UG) {
-        const int fp = u % PG, t = u / PG;
-        const f32x4 gv = R.g[i];
-        unsigned h0, l0, h1, l1;
-        x2_split2(gv[0], gv[1], s_g, h0, l0);
-        x2_split2(gv[2], gv[3], s_g, h1, l1);
-        unsigned char* d = S + fp * 2048 + t * 256;
-        *reinterpret_cast<x2u32x2*>(d) = x2u32x2{h0, h1};
-        *reinterpret_cast<x2u32x2*>(d + GPLANE) = x2u32x2{l0, l1};
-        if (do_bias) { bsum[i % NB][0] += gv[0]; bsum[i % NB][1] += gv[1]; bsum[i % NB][2] += gv[2]; bsum[i % NB][3] += gv[3]; }
-      }
+      const int fp = wave + NW * (i % NB), t = i / NB;
+      const f32x4 gv = R.g[i];
+      unsigned h0, l0, h1, l1;
+      x2_split2(gv[0], gv[1], s_g, h0, l0);
+      x2_split2(gv[2], gv[3], s_g, h1, l1);
+      unsigned char* d = S + fp * 2048 + t * 256;
+      *reinterpret_cast<x2u32x2*>(d) = x2u32x2{h0, h1};
+      *reinterpret_cast<x2u32x2*>(d + GPLANE) = x2u32x2{l0, l1};
+      if (do_bias) { bsum[i % NB][0] += gv[0]; bsum[i % NB][1] += gv[1]; bsum[i % NB][2] += gv[2]; bsum[i % NB][3] += gv[3]; }
     }
 #pragma unroll
     for (int i = 0; i < IZ; ++i) {
       const int u = wave + NW * i;
-      if (UZ % NW == 0 || u < UZ) {
-        const int fp = u % PZ, t = u / PZ;
+      if (ZFIX || u < UZ) {
+        const int fp = ZFIX ? wave : (u & 3), t = ZFIX ? i : (u >> 2);
         const f32x4 zv = R.z[i];
         unsigned h0, l0, h1, l1;
         x2_split2(zv[0], zv[1], s_z, h0, l0);
@@ -522,38 +520,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
     return __builtin_bit_cast(f16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
   };
 
-  // two passes over the 8 Z blocks, so that at most 40 fragment registers are live beside the 128 accumulator and the
-  // staging registers: the pair products (G pair fragments of the 4 blocks held), then h h (G h fragments held)
+  // three passes over the 8 Z blocks -- pair products of rows 0-15, pair products of rows 16-31, h h -- each holding the
+  // G fragments of the wave's 4 blocks for ONE product kind: 16 + 4 fragment registers live beside the 128 accumulator and
+  // the staging registers (all three kinds at once: 48 + 12, and the allocator spills)
   auto mfma_block = [&](const int buf) {
     const unsigned char* S = smem_t + buf * STAGE;
-    {
-      f16x8 gp0[4], gp1[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        gp0[i] = frag(S + g_pr + i * 1024);
-        gp1[i] = frag(S + g_pr + 256 + i * 1024);
-      }
+    for (int ps = 0; ps < 3; ++ps) {
+      const int go = ps == 2 ? g_hh : g_pr + 256 * ps;
+      const int zo = ps == 2 ? z_hh : z_pr + 256 * ps;
+      f16x8 gf[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const f16x8 zp0 = frag(S + z_pr + j * 1024);
-        const f16x8 zp1 = frag(S + z_pr + 256 + j * 1024);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          X2_MFMA(zp0, gp0[i], acc[i][j]);
-          X2_MFMA(zp1, gp1[i], acc[i][j]);
-        }
-      }
-    }
-    {
-      f16x8 ghh[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) ghh[i] = frag(S + g_hh + i * 1024);
+      for (int i = 0; i < 4; ++i) gf[i] = frag(S + go + i * 1024);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const f16x8 zhh = frag(S + z_hh + j * 1024);
+        const f16x8 zf = frag(S + zo + j * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) X2_MFMA(zhh, ghh[i], acc[i][j]);
+        for (int i = 0; i < 4; ++i) X2_MFMA(zf, gf[i], acc[i][j]);
       }
+      __builtin_amdgcn_sched_barrier(0);               // (or the next pass's fragment reads are hoisted up here)
     }
   };
   // stage s of the split into the staging registers: a full stage, the ragged tail, or nothing
@@ -564,7 +549,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
   // late (waves 0-3): loads of stage kt + 1 | MFMAs of stage kt | split + store stage kt + 1
   // early (waves >= 4): split + store stage kt + 1 (loaded a stage ago) | loads of stage kt + 2 | MFMAs of stage kt
   // Both write buffer (kt + 1) & 1 during stage kt and read buffer kt & 1: the buffer protocol is the same.
-  const bool early = wave >= 4;
+  // (the (WM, 1) shapes stage 11 instead of 8 loads per lane: with both wave kinds in the code the allocator spills ~25
+  // registers, and a spill reload waits, in vmcnt order, for the prefetched global loads -- measured 2 x the stage time at
+  // P = 384; all their waves run the late schedule)
+  const bool early = WN == 2 && wave >= 4;
   load_any(0);
   lstore(st, 0);
   if (early) load_any(1);
@@ -594,7 +582,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
     float* red = reinterpret_cast<float*>(smem_t);       // [8 row slots][TM features]
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int fp = (wave + NW * i) % PG;
+      const int fp = wave + NW * i;
       *reinterpret_cast<f32x4*>(&red[l_rs * TM + 32 * fp + l_feat]) = bsum[i];
     }
     __syncthreads();
@@ -634,8 +622,6 @@ static int x2_tn_shape(int Pm, int Pn) {
   if (Pm % 256 == 0 && Pn % 256 == 0) return 42;
   if (Pm == 384) return 61;
   if (Pm == 448) return 71;
-  if (Pm == 320) return 51;
-  if (Pm == 192) return 31;
   return 0;
 }
 bool gemmx2_tn_applies(int Pm, int Pn) { return x2_tn_shape(Pm, Pn) != 0; }
@@ -699,8 +685,6 @@ hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float*
     case 42: return launch_x2_tn_t<4, 2>(X2_TN_ARGS);
     case 61: return launch_x2_tn_t<6, 1>(X2_TN_ARGS);
     case 71: return launch_x2_tn_t<7, 1>(X2_TN_ARGS);
-    case 51: return launch_x2_tn_t<5, 1>(X2_TN_ARGS);
-    case 31: return launch_x2_tn_t<3, 1>(X2_TN_ARGS);
     default: return hipErrorInvalidValue;
   }
 #undef X2_TN_ARGS
