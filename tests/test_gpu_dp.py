@@ -90,3 +90,43 @@ def test_two_ranks_hashed_shuffle_and_broadcast(tmp_path):
     np.testing.assert_array_equal(f0, f1)
     np.testing.assert_allclose(np.load(tmp_path / "loss_0.npy"), ref_losses, rtol=2e-4)
     assert np.abs(f0 - tr.flat.detach().cpu().numpy()).max() < 0.05 * 5e-3
+
+
+def _worker_rccl_direct(rank, world, port, out_dir):
+    """One rank, backend nccl (= RCCL), WIRE_DP_FORCE=1: the collective path stays live, FlatGradAllReducer opens its own
+    communicator (parallel.RcclDirect: ncclGetUniqueId -> broadcast of the 128 bytes -> ncclCommInitRank) and issues
+    ncclAllReduce on the compute stream."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["WIRE_DP_FORCE"] = "1"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    model, tr = _make(dev, 1)
+    assert tr.reducers[0].active and tr.reducers[0].direct is not None, "direct RCCL communicator was not set up"
+    losses = _run(tr, dev)
+    np.save(os.path.join(out_dir, "flat_direct.npy"), tr.flat.detach().cpu().numpy())
+    np.save(os.path.join(out_dir, "loss_direct.npy"), np.array(losses))
+    # the reduced buffer of a 1-rank communicator is the buffer itself: check the call really ran in place
+    t = torch.arange(1000, dtype=torch.float32, device=dev)
+    tr.reducers[0].direct.all_reduce_sum_(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float32))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_direct_rccl_allreduce_single_rank_matches_plain_run(tmp_path):
+    """ncclAllReduce through librccl.so's C ABI on the compute stream (no ProcessGroup stream
+    hand-offs).  RCCL refuses two ranks on one device, so a one-GPU box can only run the 1-rank communicator: the whole
+    plumbing (unique id, communicator, stream, in-place reduce) with a sum over one rank = the plain trajectory, bit for
+    bit.  wire_occupancy.py:137-158 is the loop being sharded."""
+    port = 29500 + (os.getpid() % 400) + 17
+    mp.spawn(_worker_rccl_direct, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    dev = torch.device("cuda", 0)
+    model, tr = _make(dev, 1)
+    losses = _run(tr, dev)
+    assert np.array_equal(np.load(tmp_path / "loss_direct.npy"), np.array(losses))
+    assert np.array_equal(np.load(tmp_path / "flat_direct.npy"), tr.flat.detach().cpu().numpy())

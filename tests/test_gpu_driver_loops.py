@@ -366,3 +366,29 @@ def test_index_range_check_is_opt_in(monkeypatch):
     with pytest.raises(ValueError):
         tr.step(torch.tensor([0, 5, 64], device="cuda"))           # 64 is outside the 8 x 8 grid
     tr.step(torch.tensor([0, 5, 63], device="cuda"))
+
+
+def test_get_layer_outputs_matches_reference_montages():
+    """``utils.get_layer_outputs`` (modules/utils.py:229-288): per-layer activation montages through the
+    per-layer HIP entry points against the montages the reference's own function produced for the same net
+    (tests/golden/make_layer_outputs_golden.py).  The montage is min-max normalised per filter, so the comparison is
+    absolute on [0, 1]."""
+    import os
+    from _util import GOLDEN, checksum, params_np
+    from wire_amd.modules import models, utils
+    z = np.load(os.path.join(GOLDEN, "layer_outputs.npz"), allow_pickle=False)
+    H, W = int(z["H"]), int(z["W"])
+    torch.manual_seed(0)
+    model = models.get_INR(nonlin="wire", in_features=2, out_features=3, hidden_features=64, hidden_layers=2,
+                           first_omega_0=5.0, hidden_omega_0=5.0, scale=5.0)
+    for k, v in params_np(model).items():
+        np.testing.assert_allclose(checksum(v), z["sd_checksum__" + k], rtol=1e-12, atol=1e-12)
+    model = model.to("cuda")
+    coords = torch.tensor(z["coords"]).to("cuda")
+    for tag, imag in (("re", False), ("im", True)):
+        got = utils.get_layer_outputs(model, coords, (H, W), nfilters_vis=9, get_imag=imag)
+        assert len(got) == 3
+        for i, m in enumerate(got):
+            ref = z[f"montage_{tag}_{i}"]
+            assert m.shape == ref.shape
+            assert np.abs(m - ref).max() <= 2e-4, f"{tag} layer {i}: {np.abs(m - ref).max():.2e}"

@@ -3,7 +3,8 @@
 Only the functions the training/eval loop of wire_image_denoise.py and
 wire_occupancy.py touch are provided: coordinate grids, PSNR, parameter count,
 normalisation, the noise model and logging.  Plotting / montage / table helpers
-are out of scope.
+are out of scope -- except ``get_layer_outputs`` + ``build_montage``, the per-layer
+visualisation query SURVEY section 8 (f)3 names.
 """
 from datetime import datetime
 
@@ -67,3 +68,50 @@ def axis_tables(H, W, T=None, style="numpy"):
             return torch.linspace(-1, 1, n)
         return torch.tensor(np.linspace(-1, 1, n).astype(np.float32))
     return ax(W), ax(H), (ax(T) if T is not None else None)
+
+
+def build_montage(images):
+    """Tile ``images`` [n, H, W] (each min-max normalised, ``normalize(.., True)``) row by row into a
+    ceil(sqrt(n))-row grid; unused cells stay 0 (modules/utils.py:131-156)."""
+    images = np.asarray(images)
+    n, H, W = images.shape
+    nrows = int(np.ceil(np.sqrt(n)))
+    ncols = int(np.ceil(n / nrows))
+    out = np.zeros((H * nrows, W * ncols), dtype=np.float32)
+    for k in range(n):
+        r, c = divmod(k, ncols)
+        out[r * H:(r + 1) * H, c * W:(c + 1) * W] = normalize(images[k], True)
+    return out
+
+
+@torch.no_grad()
+def get_layer_outputs(model, coords, imsize, nfilters_vis=16, get_imag=False):
+    """Activation images after each layer, for visualisation (modules/utils.py:229-288).  Every layer runs through its
+    own HIP entry point -- ``model.net[idx](x)`` -> wire_gabor_fwd / wire_real_layer_fwd / wire_gabor2d_fwd, the kernels
+    of the fused path -- on the previous layer's (complex) output; the rest is the reference's host-side bookkeeping:
+    the first ``nfilters_vis`` filters ('all': every filter), real or imaginary part, sign chosen so that the larger
+    excursion is positive, filters ordered by standard deviation, each min-max normalised with a white frame, tiled by
+    ``build_montage``.  Returns one montage per activation layer."""
+    H, W = imsize
+    if getattr(model, "pos_encode", False):
+        coords = model.positional_encoding(coords)
+    montages = []
+    x = coords
+    for idx in range(len(model.net) - 1):
+        x = model.net[idx](x)
+        imgs = x.reshape(1, H, W, -1)[0]
+        if nfilters_vis != 'all':
+            imgs = imgs[..., :nfilters_vis]
+        atoms = imgs.detach().cpu().numpy()
+        atoms = atoms.imag if get_imag else atoms.real
+        lo = atoms.min(0, keepdims=True).min(1, keepdims=True)
+        hi = atoms.max(0, keepdims=True).max(1, keepdims=True)
+        atoms = (1 - 2 * (abs(lo) > abs(hi))) * atoms
+        atoms = atoms[..., np.argsort(atoms.std((0, 1)))]
+        lo = atoms.min(0, keepdims=True).min(1, keepdims=True)
+        hi = atoms.max(0, keepdims=True).max(1, keepdims=True)
+        atoms = (atoms - lo) / np.maximum(1e-14, hi - lo)
+        atoms[:, [0, -1], :] = 1
+        atoms[[0, -1], :, :] = 1
+        montages.append(build_montage(np.transpose(atoms, [2, 0, 1])))
+    return montages

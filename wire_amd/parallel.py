@@ -14,10 +14,83 @@ what lets tests/test_parallel_gloo.py run it with world_size 2 on CPU.
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+class _NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+class RcclDirect:
+    """ncclAllReduce of librccl.so's C ABI issued ON THE CALLER'S HIP STREAM.
+
+    torch.distributed's NCCL process group runs every collective on a stream of its own and brackets it with events
+    against the current stream -- two cross-stream hand-offs per all-reduce, measured at ~3 % of a training step
+    (tools/dp_overhead.sh).  The gradient all-reduce of a step has nothing to overlap with when it is the step's last
+    work item before Adam, so here it is simply the next operation of the compute stream: rank 0 draws a
+    ``ncclUniqueId``, torch.distributed (whatever its backend) only broadcasts those 128 bytes, and every rank joins
+    a communicator of its own with ``ncclCommInitRank`` on its current device.  The library is the librccl.so that
+    torch itself loaded (torch/lib), so both share one HIP runtime.  xGMI transport, ring / tree choice and the
+    reduction order (identical on every rank -> replicas stay bit-identical) are RCCL's.
+    """
+
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            l = C.CDLL(path)
+            l.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
+            l.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+            l.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+            l.ncclCommDestroy.argtypes = [C.c_void_p]
+            l.ncclGetErrorString.restype = C.c_char_p
+            l.ncclGetErrorString.argtypes = [C.c_int]
+            cls._lib = l
+        return cls._lib
+
+    def __init__(self, device: torch.device, group: Optional[dist.ProcessGroup] = None):
+        l = self.lib()
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        uid = _NcclUniqueId()
+        if self.rank == 0:
+            self._check(l.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        # 128 bytes through the existing process group (device tensor for nccl, host tensor for gloo)
+        on_dev = dist.get_backend(group) == "nccl"
+        t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone()
+        t = t.to(device) if on_dev else t
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(t, src=src, group=group)
+        C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+        self.comm = C.c_void_p()
+        with torch.cuda.device(device):
+            self._check(l.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+        self.device = device
+
+    @staticmethod
+    def _check(rc: int, what: str) -> None:
+        if rc != 0:
+            raise RuntimeError(f"{what} failed: {RcclDirect.lib().ncclGetErrorString(rc).decode()} ({rc})")
+
+    def all_reduce_sum_(self, t: torch.Tensor) -> None:
+        """In-place SUM over the ranks of a contiguous float32 device tensor, on torch's current stream."""
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise ValueError("RcclDirect reduces contiguous float32 device tensors")
+        stream = torch.cuda.current_stream(t.device).cuda_stream
+        self._check(self.lib().ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), 7, 0, self.comm, stream),
+                    "ncclAllReduce")      # ncclFloat32 = 7, ncclSum = 0
+
+    def close(self) -> None:
+        if getattr(self, "comm", None) is not None and self.comm.value:
+            self.lib().ncclCommDestroy(self.comm)
+            self.comm = C.c_void_p()
 
 
 def shard_bounds(batch: int, world: int, rank: int) -> Tuple[int, int]:
@@ -48,13 +121,16 @@ class FlatGradAllReducer:
     process group degrades to a no-op (world size 1).
     """
 
+    # one direct communicator per (device, group): the reducers of several micro-shards / trainers share it
+    _direct_comms = {}
+
     def __init__(self, flat: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
                  bucket_floats: Optional[int] = None, use_side_stream: bool = True):
         self.flat = flat
         self.group = group
+        self.direct: Optional[RcclDirect] = None
         # WIRE_DP_FORCE=1 keeps the collective path live with a single rank (rehearsal of the RCCL
         # stream plumbing on a one-GPU box)
-        import os
         force = os.environ.get("WIRE_DP_FORCE", "0") == "1"
         self.active = dist.is_available() and dist.is_initialized() and \
             (dist.get_world_size(group) > 1 or force)
@@ -70,12 +146,40 @@ class FlatGradAllReducer:
         if self.active and flat.is_cuda and use_side_stream and not self.stage_host:
             self.stream = torch.cuda.Stream(device=flat.device)
         self._pending: List = []
+        # RCCL backend, collective on the compute stream: ncclAllReduce straight from here (RcclDirect) instead of
+        # through the process group's own stream; WIRE_DP_DIRECT=0 keeps torch.distributed.all_reduce.  Any failure to
+        # set the communicator up falls back to the process group (every rank takes the same branch: the outcome is
+        # agreed on with a MIN all-reduce).
+        if (self.active and flat.is_cuda and self.stream is None and not self.stage_host
+                and dist.get_backend(group) == "nccl" and os.environ.get("WIRE_DP_DIRECT", "1") != "0"):
+            key = (flat.device.index, id(group))
+            comm = FlatGradAllReducer._direct_comms.get(key)
+            if comm is None:
+                ok = torch.ones(1, device=flat.device)
+                try:
+                    comm = RcclDirect(flat.device, group)
+                except Exception as e:                      # noqa: BLE001 -- any failure means "use the process group"
+                    import warnings
+                    warnings.warn(f"direct RCCL communicator unavailable ({e}); using torch.distributed.all_reduce")
+                    ok.zero_()
+                    comm = None
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+                if float(ok.item()) < 1.0:
+                    if comm is not None:
+                        comm.close()
+                    comm = None
+                FlatGradAllReducer._direct_comms[key] = comm if comm is not None else False
+            self.direct = comm if comm else None
 
     def launch(self, tensor: Optional[torch.Tensor] = None) -> None:
         """Start the all-reduce of ``tensor`` (default: the flat buffer)."""
         if not self.active:
             return
         t = self.flat if tensor is None else tensor
+        if self.direct is not None:
+            for lo, hi in self.buckets:
+                self.direct.all_reduce_sum_(t[lo:hi])
+            return
         if self.stage_host:
             host = t.detach().cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
