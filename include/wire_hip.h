@@ -294,8 +294,7 @@ int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* 
  *     wire_train_fwd_bwd (whose last hidden layer then does not store out at all).  0 = read the stored activations.
  * "first_sums" (default 1): wire nets on the 16x16x32 kernels -- the epilogue of the last data-gradient GEMM forms the
  *     first layer's per-tile gradient sums itself instead of storing g_u for a separate reduction pass.
- * "x3_glds" (default 0): 1 / 2 = LDS-DMA 32x32x16 editions of the split-bf16 NT GEMM at M >= 4096
- *     (wire_gemmx3g.hip).  All editions give bit-identical GEMM results.
+ * (The LDS-DMA 32x32x16 edition of round 2, "x3_glds", left the library: tools/wire_gemmx3g.hip, harness builds only.)
  * Buffer sizes (wire_packed_floats, wire_act_bytes, wire_bwd_scratch_bytes) and the layout of packed weights do not
  * depend on the knobs: wire_pack_params writes the weight image of every family, activations are fp32 blocked rows for
  * all of them.  The knobs must NOT change between a forward and the backward that consumes its activation buffer: the

@@ -104,19 +104,24 @@ extern "C" int wire_prof_read(double* ms_total, int64_t* launches, double* flops
 // ---------------------------------------------------------------------------
 // wire training step on the 16 x 16 x 32 kernels: backward passes evaluate out = act(lin) again instead of reading it
 // (the data-gradient epilogues and the fused final stage), and the last hidden layer does not store out at all
-static int g_recompute_out = [] { const char* v = getenv("WIRE_RECOMPUTE_OUT"); return v ? atoi(v) : 1; }();
-static int g_first_sums = [] { const char* v = getenv("WIRE_FIRST_SUMS"); return v ? atoi(v) : 1; }();
-static int g_complex_3m = 1;   // wire: 3-multiplication complex GEMMs on the fp32 MFMA (wire_gemm3m.hip)
+static int env_int_(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+// (relaxed atomics: wire_tune_set may run on one thread while autograd's thread reads a knob inside a launch sequence)
+static std::atomic<int> g_recompute_out{env_int_("WIRE_RECOMPUTE_OUT", 1)};
+static std::atomic<int> g_first_sums{env_int_("WIRE_FIRST_SUMS", 1)};
+static std::atomic<int> g_complex_3m{1};   // wire: 3-multiplication complex GEMMs on the fp32 MFMA (wire_gemm3m.hip)
 static int env_flag(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? (atoi(v) != 0) : dflt;
 }
 // every net: split-bf16 GEMMs on the bf16 MFMA (wire_gemmx3.hip); overrides complex_3m
-static int g_split_bf16 = env_flag("WIRE_SPLIT_BF16", 1);
+static std::atomic<int> g_split_bf16{env_flag("WIRE_SPLIT_BF16", 1)};
 // hidden-layer GEMMs of batches >= 4096 rows as a 2 x fp16 split on the f16 MFMA (wire_gemmx2h.hip): 3 instead of 6
 // matrix-core products per fp32 product, operand scales from device-side maxima; needs split_bf16 and the 16 x 16 x 32
 // kernels (x3_h16) for the net kind, falls back to the 3 x bf16 kernels otherwise
-static int g_split_f16 = env_flag("WIRE_SPLIT_F16", 1);
+static std::atomic<int> g_split_f16{env_flag("WIRE_SPLIT_F16", 1)};
 // family the flags select for a net kind (wire_layer_api.hip): 2 split-bf16, 1 complex 3M (wire only), 0 4M
 int wire_family_(int kind) {
   if (g_split_bf16) return 2;

@@ -92,7 +92,12 @@ int gemmx3_tn_splits_max(int64_t n, int Pm, int Pn, int max_splits);   // over t
 hipError_t launch_gemmx3_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n,
                             int Pm, int Pn, int splits, float* slab, float* bslab);
 
-// ---- LDS-DMA edition of the split-bf16 NT GEMM for large batches (wire_gemmx3g.hip); same operands and image
+// ---- LDS-DMA 32 x 32 x 16 edition of the split-bf16 NT GEMM (tools/wire_gemmx3g.hip, harness builds only; it registers
+// itself with launch_gemmx3_nt's dispatch); same operands and image
+void gemmx3_register_glds(bool (*handles)(int, int64_t),
+                          hipError_t (*launch)(hipStream_t, int, const float*, int, const void*, int64_t, int, int,
+                                               const GemmEpiParams&),
+                          int (*tune)(const char*, int));
 bool gemmx3g_handles(int epi, int64_t M);
 int gemmx3g_tune_set(const char* key, int value);
 int gemmx3g_mode();

@@ -24,6 +24,7 @@
 // nets (siren / gauss / relu), wire2d, the per-layer API and complex_3m=0.  The
 // default path of `wire` layers is the 3-multiplication form in wire_gemm3m.hip.
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 
 #include "wire_dev.h"
@@ -191,7 +192,7 @@ static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
 }
-static int g_nt_bk = env_int("WIRE_NT_BK", 16);   // K-slab depth of the NT kernel: 16 or 32
+static std::atomic<int> g_nt_bk{env_int("WIRE_NT_BK", 16)};   // K-slab depth of the NT kernel: 16 or 32
 static int nt_bk() { return g_nt_bk; }
 int gemm_tune_set(const char* key, int value) {
   if (!strcmp(key, "nt_bk") && (value == 16 || value == 32)) { g_nt_bk = value; return 0; }

@@ -36,6 +36,7 @@
 // Replaces the ATen complex addmm / mm of modules/wire.py:89 and of its autograd backward (and the real addmm of
 // modules/siren.py:49, gauss.py:28, relu.py:29, wire2d.py:57-58) at M >= 4096.
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 
 #include "wire_dev.h"
@@ -304,7 +305,7 @@ static int x2_env(const char* name, int dflt) {
 // and dropped (profiles/r03_gemm_x2_prefetch_ablation.txt): an L2 prefetch of the rows three stages ahead (+ 0.02 ms: the
 // cost of the HBM reads is not their latency -- with every A row served from cache the store form takes 0.347 ms, i.e. the
 // 0.54 GB of A cost 0.105 ms, what they cost at 5 TB/s beside a matrix pipe that shares the chip's power budget).
-static int g_x2_amode = x2_env("WIRE_X2_AMODE", 1);
+static std::atomic<int> g_x2_amode{x2_env("WIRE_X2_AMODE", 1)};
 int gemmx2h_tune_set(const char* key, int value) {
   if (!strcmp(key, "x2_amode") && (value == 0 || value == 1)) { g_x2_amode = value; return 0; }
   return -1;

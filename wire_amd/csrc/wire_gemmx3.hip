@@ -27,6 +27,7 @@
 // Replaces the ATen complex addmm / mm of modules/wire.py:89 and of its autograd backward (and the real
 // addmm of modules/siren.py:49, gauss.py:28, relu.py:29, wire2d.py:57-58).
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 
 #include "wire_dev.h"
@@ -368,30 +369,44 @@ static int x3_env(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
 }
-static int g_x3_tn_tall = x3_env("WIRE_X3_TN_TALL", 0);   // 256 x 128 tiles in the weight-gradient kernel
-static int g_x3_tn16 = x3_env("WIRE_X3_TN16", 1);         // 256 x 256 tiles on v_mfma_f32_16x16x32_bf16
+static std::atomic<int> g_x3_tn_tall{x3_env("WIRE_X3_TN_TALL", 0)};   // 256 x 128 tiles in the weight-gradient kernel
+static std::atomic<int> g_x3_tn16{x3_env("WIRE_X3_TN16", 1)};         // 256 x 256 tiles on v_mfma_f32_16x16x32_bf16
 // 256-row tiles (4 x 2 MFMA tiles per wave) for the Gabor epilogues of large batches: fewer weight bytes
 // per MFMA through the 64 B/clk L1 path (tools/mfma_bf16_probe.hip), 7-9 % faster at N = 262144
-static int g_x3_tall = x3_env("WIRE_X3_TALL", 1);
-static int g_x3_tall_real = x3_env("WIRE_X3_TALL_REAL", 0);   // the same for siren / gauss / relu (A/B switch)
+static std::atomic<int> g_x3_tall{x3_env("WIRE_X3_TALL", 1)};
+static std::atomic<int> g_x3_tall_real{x3_env("WIRE_X3_TALL_REAL", 0)};   // the same for siren / gauss / relu (A/B switch)
 int gemmx3_tn16_mode() { return g_x3_tn16; }
+// The LDS-DMA 32 x 32 x 16 edition (tools/wire_gemmx3g.hip: the staging A/B of round 2) lives outside the product library;
+// a harness that links it registers it here.
+static bool (*g_glds_handles)(int, int64_t) = nullptr;
+static hipError_t (*g_glds_launch)(hipStream_t, int, const float*, int, const void*, int64_t, int, int,
+                                   const GemmEpiParams&) = nullptr;
+static int (*g_glds_tune)(const char*, int) = nullptr;
+void gemmx3_register_glds(bool (*handles)(int, int64_t),
+                          hipError_t (*launch)(hipStream_t, int, const float*, int, const void*, int64_t, int, int,
+                                               const GemmEpiParams&),
+                          int (*tune)(const char*, int)) {
+  g_glds_handles = handles; g_glds_launch = launch; g_glds_tune = tune;
+}
 int gemmx3_tune_set(const char* key, int value) {
   if (!strcmp(key, "x3_tall") && (value == 0 || value == 1)) { g_x3_tall = value; return 0; }
   if (!strcmp(key, "x3_tn_tall") && (value == 0 || value == 1)) { g_x3_tn_tall = value; return 0; }
   if (!strcmp(key, "x3_tn16") && (value == 0 || value == 1)) { g_x3_tn16 = value; return 0; }
   if (!strcmp(key, "x3_tall_real") && (value == 0 || value == 1)) { g_x3_tall_real = value; return 0; }
   if (gemmx3h_tune_set(key, value) == 0) return 0;
-  return gemmx3g_tune_set(key, value);
+  return g_glds_tune ? g_glds_tune(key, value) : -1;
 }
 
 // true when launch_gemmx3_nt runs this epilogue on the 16 x 16 x 32 edition (lean epilogues, optional out store,
 // recompute_out) at M rows under the current knobs
-bool gemmx3_nt_is_h16(int epi, int64_t M) { return !gemmx3g_handles(epi, M) && gemmx3h_handles(epi, M); }
+bool gemmx3_nt_is_h16(int epi, int64_t M) {
+  return !(g_glds_handles && g_glds_handles(epi, M)) && gemmx3h_handles(epi, M);
+}
 
 hipError_t launch_gemmx3_nt(hipStream_t s, int epi, const float* A, int lda, const void* Bx3, int64_t M,
                             int Nc, int Kd, const GemmEpiParams& ep_in) {
   if (M <= 0) return hipSuccess;
-  if (gemmx3g_handles(epi, M)) return launch_gemmx3g_nt(s, epi, A, lda, Bx3, M, Nc, Kd, ep_in);   // LDS-DMA edition
+  if (g_glds_handles && g_glds_handles(epi, M)) return g_glds_launch(s, epi, A, lda, Bx3, M, Nc, Kd, ep_in);   // harness only
   if (gemmx3h_handles(epi, M)) return launch_gemmx3h_nt(s, epi, A, lda, Bx3, M, Nc, Kd, ep_in);   // 16 x 16 x 32 edition
   if ((Nc & 63) || (Kd & 31) || (lda & 3) || M > 0x7fffff00LL) return hipErrorInvalidValue;
   // the lean Gabor epilogues share one 32-bit byte offset between their buffers

@@ -32,6 +32,7 @@
 //
 // Replaces the ATen complex addmm / mm of modules/wire.py:89 and of its autograd backward at M >= 4096.
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 
 #include "wire_dev.h"
@@ -241,8 +242,8 @@ static int x3h_env(const char* name, int dflt) {
 // profiles/r02_bench_h16_ab.txt): forward launches 0.758 -> 0.700 ms, data gradient 0.749 -> 0.739 ms, step 9.93 -> 9.63 ms
 // bit 2: siren / gauss / relu epilogues, bit 3: the 2-D Gabor epilogues (sweep A/B, same box: siren 72.4 -> 74.9,
 // relu 81.9 -> 85.0, wire2d 44.2 -> 47.6 M samples/s)
-static int g_x3_h16 = x3h_env("WIRE_X3_H16", 15);
-static int g_x3h_stagger = x3h_env("WIRE_X3H_STAGGER", 0);      // 100 MHz ticks (100 = 1 us)
+static std::atomic<int> g_x3_h16{x3h_env("WIRE_X3_H16", 15)};
+static std::atomic<int> g_x3h_stagger{x3h_env("WIRE_X3H_STAGGER", 0)};      // 100 MHz ticks (100 = 1 us)
 int gemmx3h_tune_set(const char* key, int value) {
   if (!strcmp(key, "x3_h16") && value >= 0 && value <= 15) { g_x3_h16 = value; return 0; }
   if (!strcmp(key, "x3h_stagger") && value >= 0) { g_x3h_stagger = value; return 0; }
