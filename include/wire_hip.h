@@ -260,6 +260,12 @@ int wire_gabor2d_hparam_grad(void* stream, const void* g_act, const void* x, con
                              const void* V, const void* c, float omega0, float scale0, int64_t n, int in_features,
                              int out_features, int is_first, float* out2, void* ws, int64_t ws_bytes);
 
+/* ---- positional encoding (PosEncoding.forward, modules/relu.py:62-75) ----
+ * out[n][D + 2 D F]: the raw coordinates, then for each frequency i < F and dimension j < D: sin(2^i pi c_j),
+ * cos(2^i pi c_j) (the product 2^i pi c_j rounded to fp32 first, as the reference's python-float x tensor is).  The
+ * whole-net path (wire_mlp_fwd with posenc_freqs > 0) runs the same kernel into its padded first-layer input.   */
+int wire_posenc_fwd(void* stream, const float* coords, int64_t n, int D, int F, float* out);
+
 /* ---- layout helpers ---------------------------------------------------- */
 int wire_blocked_width(int K);   /* P = roundup(2K, 64) */
 int wire_c64_to_blocked(void* stream, const void* src, int64_t n, int K, float* dst);

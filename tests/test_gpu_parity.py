@@ -729,3 +729,19 @@ def test_wire2d_layer_backward_matches_autograd(is_first):
     r64, r32 = ref(True), ref(False)
     for k in got:
         within_ref(relmax(got[k], r64[k]), relmax(r32[k], r64[k]), f"wire2d layer is_first={is_first} {k}")
+
+
+def test_posenc_module_matches_reference_known_answer():
+    """PosEncoding.forward (modules/relu.py:62-75) through wire_posenc_fwd -- the HIP kernel of the fused path's first-layer
+    prologue -- against the reference-generated vector of tests/golden/misc.npz, and against the oracle on a grid."""
+    from _util import load_golden
+    from wire_amd.modules.relu import PosEncoding
+    misc = load_golden("misc")
+    pe = PosEncoding(2, sidelength=512)
+    got = pe(torch.tensor(misc["posenc2_in"]).to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(got, misc["posenc2_out"], atol=1e-6)
+    c = wo.image_coords(33, 47)[None]
+    got = pe(torch.tensor(c).to(DEV)).cpu().numpy()
+    ref = wo.posenc(c.astype(np.float64), pe.num_frequencies)
+    assert got.shape == ref.shape == (1, 33 * 47, 30)
+    assert np.abs(got - ref).max() <= 2e-5          # 2^6 pi c rounded to fp32 before sin / cos, as in the reference

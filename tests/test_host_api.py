@@ -128,9 +128,14 @@ def test_utils_match_reference_known_answers():
     tx, ty, _ = utils.axis_tables(5, 7, style="torch")
     np.testing.assert_array_equal(tx.numpy(), misc["linspace_7"])
     np.testing.assert_array_equal(ty.numpy(), misc["linspace_5"])
+    # (PosEncoding.forward runs on the device -- wire_posenc_fwd; its known answer is checked in tests/test_gpu_parity.py)
     from wire_amd.modules.relu import PosEncoding
+    from wire_amd._lib import WireHipError
+    import pytest
     pe = PosEncoding(2, sidelength=512)
-    np.testing.assert_allclose(pe(torch.tensor(misc["posenc2_in"])).numpy(), misc["posenc2_out"], atol=1e-6)
+    assert pe.num_frequencies == 7 and pe.out_dim == 30
+    with pytest.raises(WireHipError):
+        pe(torch.tensor(misc["posenc2_in"]))
 
 
 def test_fused_trainer_rejects_layerwise_and_trainable_nets():

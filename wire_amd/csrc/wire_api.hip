@@ -839,6 +839,12 @@ extern "C" int wire_radon_bwd(void* stream, const float* g_sino, const float* an
   HIPCHK(launch_radon_bwd((hipStream_t)stream, g_sino, angles_deg, H, W, nangles, g_img));
   return WIRE_OK;
 }
+extern "C" int wire_posenc_fwd(void* stream, const float* coords, int64_t n, int D, int F, float* out) {
+  if (n < 0 || D < 1 || D > 4 || F < 0 || F > 30 || (n > 0 && (!coords || !out)))
+    return fail(WIRE_ERR_ARG, "bad argument to wire_posenc_fwd");
+  HIPCHK(launch_posenc((hipStream_t)stream, coords, n, D, F, D + 2 * D * F, out));
+  return WIRE_OK;
+}
 extern "C" int wire_sigmoid_inplace(void* stream, float* x, int64_t count) {
   if (count < 0 || (count > 0 && !x)) return fail(WIRE_ERR_ARG, "bad argument to wire_sigmoid_inplace");
   HIPCHK(launch_sigmoid((hipStream_t)stream, x, count));

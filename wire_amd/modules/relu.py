@@ -66,13 +66,18 @@ class PosEncoding(nn.Module):
         return int(math.floor(math.log(nyquist_rate, 2)))
 
     def forward(self, coords):
-        coords = coords.view(coords.shape[0], -1, self.in_features)
-        feats = [coords]
-        for i in range(self.num_frequencies):
-            arg = (2 ** i) * np.pi * coords                       # [B, N, D]
-            feats.append(torch.stack((torch.sin(arg), torch.cos(arg)), dim=-1)
-                         .reshape(coords.shape[0], coords.shape[1], -1))
-        return torch.cat(feats, dim=-1).reshape(coords.shape[0], -1, self.out_dim)
+        """modules/relu.py:62-75 on the device: ``wire_posenc_fwd`` (the kernel the fused path runs as its first-layer
+        prologue).  No gradient flows to the coordinates (no caller in the reference asks for one)."""
+        import ctypes  # noqa: F401
+        from .. import _lib
+        if not coords.is_cuda:
+            raise _lib.WireHipError(f"PosEncoding input is on {coords.device}; wire_amd runs on an MI355X only")
+        x = coords.detach().to(torch.float32).reshape(coords.shape[0], -1, self.in_features).contiguous()
+        B, n = x.shape[0], x.shape[1]
+        out = torch.empty(B, n, self.out_dim, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().wire_posenc_fwd(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), B * n,
+                                              self.in_features, self.num_frequencies, out.data_ptr()), "wire_posenc_fwd")
+        return out
 
 
 class INR(HipINR):
