@@ -268,6 +268,11 @@ int wire_posenc_fwd(void* stream, const float* coords, int64_t n, int D, int F, 
 
 /* ---- layout helpers ---------------------------------------------------- */
 int wire_blocked_width(int K);   /* P = roundup(2K, 64) */
+/* Float offset of the stored activations out_l (n rows of P floats -- blocked planar for wire / wire2d, P = roundup(K, 64)
+ * plain features for siren / gauss / relu; l = 0..hidden_layers) inside an act buffer that wire_mlp_fwd / wire_train_fwd_bwd
+ * filled for n rows with save_for_bwd = 1: the per-layer activations of modules/utils.py:246-252 without re-running the
+ * layers.  (With recompute_out the last hidden layer of a fused training step is not stored, except for relu.)          */
+int64_t wire_act_out_offset(const wire_net_desc* d, int64_t n, int layer);
 int wire_c64_to_blocked(void* stream, const void* src, int64_t n, int K, float* dst);
 int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* dst);
 

@@ -317,7 +317,10 @@ def realnet_forward(kind: str, params: Params, coords, hidden_layers,
 
 
 def realnet_backward(kind: str, params: Params, cache, g_y, hidden_layers,
-                     first_omega0, hidden_omega0, scale0) -> Params:
+                     first_omega0, hidden_omega0, scale0, relu_masks=None) -> Params:
+    """``relu_masks`` (relu only; one boolean array per layer 0..L, or None): use these ``lin > 0`` decisions instead of
+    the cache's own.  The gradient of relu is discontinuous at lin = 0, so two correct implementations disagree on
+    elements whose lin is round-off; a comparison of their gradients is meaningful only on identical decisions."""
     L = hidden_layers
     grads: Params = {}
     gy = g_y.reshape(-1, g_y.shape[-1])
@@ -333,8 +336,11 @@ def realnet_backward(kind: str, params: Params, cache, g_y, hidden_layers,
         zin = cache["x"] if l == 0 else cache["out"][l - 1]
         zin = zin.reshape(-1, zin.shape[-1])
         W = params[f"net.{l}.linear.weight"]
-        g_lin = real_act_grad(kind, g_out, lin, out,
-                              first_omega0 if l == 0 else hidden_omega0, scale0)
+        if relu_masks is not None and kind == "relu":
+            g_lin = g_out * relu_masks[l].reshape(lin.shape)
+        else:
+            g_lin = real_act_grad(kind, g_out, lin, out,
+                                  first_omega0 if l == 0 else hidden_omega0, scale0)
         grads[f"net.{l}.linear.weight"] = g_lin.T @ zin
         grads[f"net.{l}.linear.bias"] = g_lin.sum(0)
         if l > 0:

@@ -155,14 +155,16 @@ def _host_threads():
     return max(1, min(n, 16))
 
 
-def oracle_grads_chunked(kind, P, coords, target, L, om1, om, sc, double, nf=None, chunk=16384):
+def oracle_grads_chunked(kind, P, coords, target, L, om1, om, sc, double, nf=None, chunk=16384, relu_masks=None):
     """Loss and every parameter gradient of the MSE over ALL rows (mean over n x O elements,
     wire_image_denoise.py:153), evaluated by the numpy oracle in row chunks so that BASELINE.json's full batches
     (262 144 x 256 complex128 activations = 0.5 GB per layer; 1 048 576 rows for wire2d) stay small; the chunks run on
     a thread pool (numpy releases the GIL; one BLAS thread per worker) and are summed in chunk order, in the chunk's
     own precision.  kind: 'wire' (modules/wire.py:161-167), 'wire2d' (modules/wire2d.py:56-67,124-130), 'siren' /
     'gauss' / 'relu' (modules/siren.py:90-96, gauss.py:71-74, relu.py:124-130; ``nf`` = number of positional-encoding
-    frequencies, relu.py:62-75, or None).  Returns (y, loss, grads)."""
+    frequencies, relu.py:62-75, or None).  ``relu_masks``: per-layer boolean [n, K] arrays forcing the relu decisions
+    (oracle.realnet_backward); the returned dict then also holds "flips" = the number of forced decisions that differ from
+    the oracle's own and "flip_lin_max" = the largest |lin| among them.  Returns (y, loss, grads)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import wire_oracle as wo
     rdt = np.float64 if double else np.float32
@@ -187,7 +189,17 @@ def oracle_grads_chunked(kind, P, coords, target, L, om1, om, sc, double, nf=Non
         elif kind == "wire2d":
             g = wo.wire2d_backward(p, cache, gy, L, *a)
         else:
-            g = wo.realnet_backward(kind, p, cache, gy, L, *a)
+            mk = None if relu_masks is None else [m[s:s + chunk] for m in relu_masks]
+            g = wo.realnet_backward(kind, p, cache, gy, L, *a, relu_masks=mk)
+            if mk is not None:
+                fl, fm = 0, 0.0
+                for l, m in enumerate(mk):
+                    d = m != (cache["lin"][l] > 0)
+                    fl += int(d.sum())
+                    if d.any():
+                        fm = max(fm, float(np.abs(cache["lin"][l][d]).max()))
+                g = dict(g)
+                g["__flips"] = np.array([fl, fm], np.float64)
         return y, sq, g
 
     starts = list(range(0, n, chunk))
@@ -206,10 +218,16 @@ def oracle_grads_chunked(kind, P, coords, target, L, om1, om, sc, double, nf=Non
                 limit.restore_original_limits()
     else:
         parts = [one(s) for s in starts]
-    grads, sq = None, 0.0
+    grads, sq, flips, flipmax = None, 0.0, 0, 0.0
     for _, q, g in parts:
         sq += q
+        if "__flips" in g:
+            g = dict(g)
+            f = g.pop("__flips")
+            flips += int(f[0]); flipmax = max(flipmax, float(f[1]))
         grads = g if grads is None else {k: grads[k] + g[k] for k in g}
+    if relu_masks is not None:
+        grads["flips"], grads["flip_lin_max"] = flips, flipmax
     return np.concatenate([y for y, _, _ in parts], 0), sq / (n * O), grads
 
 

@@ -337,8 +337,27 @@ def test_fused_trainer_step_every_kind_vs_fp64_oracle_at_bench_size(case):
     om = kw.get("hidden_omega_0", 30.0)
     sc = kw.get("scale", 10.0)
     nf = wo.posenc_num_frequencies(Dn, kw["sidelength"]) if kw.get("pos_encode") else None
-    y64, l64, g64 = oracle_grads_chunked(kind, P, coords, tgt, Ln, om1, om, sc, True, nf)
-    y32, l32, g32 = oracle_grads_chunked(kind, P, coords, tgt, Ln, om1, om, sc, False, nf)
+    masks = None
+    if kind == "relu":
+        # relu's gradient is discontinuous at lin = 0: an element whose lin is round-off gets g_out from one correct fp32
+        # implementation and 0 from another, and ONE such element moves a 262 144-row gradient sum by 4e-6 of its maximum.
+        # As in the per-layer test (test_real_layers_identical_inputs_at_timed_shape) the comparison runs on identical
+        # decisions: the build's own (out_l > 0, read back from its activation buffer) are imposed on both oracles; the
+        # decisions that differ from the fp64 oracle's must be few and all at |lin| = round-off.
+        from wire_amd import _lib
+        act = tr.act.view(torch.float32)
+        K = model._arch["width"]
+        masks = []
+        for l in range(Ln + 1):
+            off = _lib.check(_lib.lib().wire_act_out_offset(C.byref(tr.desc), N, l))
+            masks.append((act[off:off + N * K].view(N, K) > 0).cpu().numpy())
+    y64, l64, g64 = oracle_grads_chunked(kind, P, coords, tgt, Ln, om1, om, sc, True, nf, relu_masks=masks)
+    y32, l32, g32 = oracle_grads_chunked(kind, P, coords, tgt, Ln, om1, om, sc, False, nf, relu_masks=masks)
+    if masks is not None:
+        flips, flipmax = g64.pop("flips"), g64.pop("flip_lin_max")
+        g32.pop("flips"), g32.pop("flip_lin_max")
+        print(f"{case}: {flips} relu decisions of {N * K * (Ln + 1)} differ from the fp64 oracle's, largest |lin| {flipmax:.2e}")
+        assert flips <= 1e-5 * N * K * (Ln + 1) and flipmax <= 2e-5
     tag = f"step[{case}]"
     err_y_ref = relmax(y32, y64)
     within_ref(relmax(tr.rec.cpu().numpy()[perm.numpy()], y64), err_y_ref, tag + " y")

@@ -28,7 +28,7 @@ SYMBOLS = [
     "wire_layer_ws_bytes", "wire_gabor_fwd", "wire_gabor_bwd", "wire_final_fwd",
     "wire_final_bwd", "wire_coords_from_index", "wire_mse_grad",
     "wire_adam_step_flat", "wire_blocked_width", "wire_c64_to_blocked",
-    "wire_blocked_to_c64", "wire_prof_enable", "wire_prof_read", "wire_tune_set", "wire_tune_get", "wire_avgpool_mse_grad", "wire_layer2d_ws_bytes", "wire_gabor2d_fwd", "wire_gabor2d_bwd", "wire_eval_metric", "wire_real_layer_fwd", "wire_real_layer_bwd", "wire_train_fwd_bwd", "wire_perm_indices", "wire_gabor_hparam_grad", "wire_track_best", "wire_sigmoid_inplace", "wire_radon_fwd", "wire_radon_bwd", "wire_gabor2d_hparam_grad", "wire_posenc_fwd",
+    "wire_blocked_to_c64", "wire_prof_enable", "wire_prof_read", "wire_tune_set", "wire_tune_get", "wire_avgpool_mse_grad", "wire_layer2d_ws_bytes", "wire_gabor2d_fwd", "wire_gabor2d_bwd", "wire_eval_metric", "wire_real_layer_fwd", "wire_real_layer_bwd", "wire_train_fwd_bwd", "wire_perm_indices", "wire_gabor_hparam_grad", "wire_track_best", "wire_sigmoid_inplace", "wire_radon_fwd", "wire_radon_bwd", "wire_gabor2d_hparam_grad", "wire_posenc_fwd", "wire_act_out_offset",
 ]
 
 
@@ -72,6 +72,8 @@ def _declare(l: C.CDLL) -> None:
     l.wire_track_best.argtypes = [vp, vp, vp, i32, vp, vp, i64, vp]
     l.wire_sigmoid_inplace.argtypes = [vp, vp, i64]
     l.wire_posenc_fwd.argtypes = [vp, vp, i64, i32, i32, vp]
+    l.wire_act_out_offset.argtypes = [dp, i64, i32]
+    l.wire_act_out_offset.restype = i64
     l.wire_radon_fwd.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     l.wire_radon_bwd.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     l.wire_final_fwd.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, vp, i64]

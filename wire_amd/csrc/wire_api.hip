@@ -361,6 +361,12 @@ extern "C" int64_t wire_bwd_scratch_bytes(const wire_net_desc* d, int64_t n) {
   return scratch_layout(p, n).total * 4 + 256;
 }
 extern "C" int wire_blocked_width(int K) { return rup(2 * K, 64); }
+// float offset of out_l (rows of P floats, l = 0..L) inside an act buffer laid out for n rows with save_for_bwd = 1
+extern "C" int64_t wire_act_out_offset(const wire_net_desc* d, int64_t n, int layer) {
+  Plan p; if (make_plan(d, p)) return WIRE_ERR_ARG;
+  if (n < 0 || layer < 0 || layer > p.L) return fail(WIRE_ERR_ARG, "bad argument to wire_act_out_offset");
+  return act_layout(p, n, 1).out0 + (int64_t)layer * n * p.P;
+}
 
 // ---------------------------------------------------------------------------
 // pack

@@ -621,7 +621,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
 static int x2_tn_shape(int Pm, int Pn) {
   if ((Pm & 63) || (Pn & 63) || Pm < 64 || Pn < 64) return 0;
   if (Pm % 256 == 0 && Pn % 256 == 0) return 42;
-  if (Pm == 384) return 61;
+  // (6, 1) for P = 384 (K = 181) is built and correct but measured SLOWER than the 128 x 128 3 x bf16 kernel at that width
+  // (0.609 against 0.578 ms, profiles/r03_gemm_x2_tn_shapes.txt; (7, 1) at P = 448: 0.497 against 0.858): off unless
+  // WIRE_X2_TN61=1
+  static const int tn61 = x2_env("WIRE_X2_TN61", 0);
+  if (Pm == 384 && tn61) return 61;
   if (Pm == 448) return 71;
   return 0;
 }

@@ -33,12 +33,24 @@ def get_I_and_U(preds, gt, thres=None):
         p.masked_fill_(p >= thres, 1.0)
     # without a threshold the reference's logical_and / logical_or test for non-zero (either sign)
     flat = p.to(torch.float32).contiguous() if thres is not None else (p != 0).to(torch.float32).contiguous()
+    # exact integer counts, as the reference's logical_and(...).sum(): the device reduction accumulates in fp32, which
+    # holds every integer up to 2^24, so the volume goes in slabs of at most 2^24 voxels (a 512^3 volume has 2^27) whose
+    # counts are converted to int64 before they are added up -- all on the device, no host sync
     out = torch.empty(2, dtype=torch.float32, device=p.device)
     partial = torch.empty(4096, dtype=torch.float32, device=p.device)
-    # the volume now holds 0 / 1: counting "pred >= 0.5" counts its ones
-    _lib.check(L.wire_eval_metric(torch.cuda.current_stream(p.device).cuda_stream, 1, flat.data_ptr(), g.data_ptr(),
-                                  flat.numel(), 0.5, out.data_ptr(), partial.data_ptr()), "wire_eval_metric")
-    return out[0], out[1]
+    flat, g = flat.reshape(-1), g.reshape(-1)
+    inter = torch.zeros((), dtype=torch.int64, device=p.device)
+    union = torch.zeros((), dtype=torch.int64, device=p.device)
+    stream = torch.cuda.current_stream(p.device).cuda_stream
+    for b in range(0, flat.numel(), 1 << 24):
+        n = min(1 << 24, flat.numel() - b)
+        # the volume now holds 0 / 1: counting "pred >= 0.5" counts its ones
+        _lib.check(L.wire_eval_metric(stream, 1, flat.data_ptr() + 4 * b, g.data_ptr() + 4 * b, n, 0.5, out.data_ptr(),
+                                      partial.data_ptr()), "wire_eval_metric")
+        cnt = out.to(torch.int64)
+        inter = inter + cnt[0]
+        union = union + cnt[1]
+    return inter, union
 
 
 def get_IoU(preds, gt, thres=None):
@@ -47,7 +59,7 @@ def get_IoU(preds, gt, thres=None):
     return intersection / union
 
 
-def get_IoU_batch(preds, gt, thres=None, maxpoints=int(50e6)):
+def get_IoU_batch(preds, gt, thres=None, maxpoints=pow(2, 24)):
     """modules/volutils.py:54-71: IoU accumulated over slabs of ``maxpoints`` voxels."""
     preds, gt = preds.flatten(), gt.flatten()
     inter, union = [], []
