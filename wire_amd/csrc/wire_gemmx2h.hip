@@ -621,22 +621,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
 static int x2_tn_shape(int Pm, int Pn) {
   if ((Pm & 63) || (Pn & 63) || Pm < 64 || Pn < 64) return 0;
   if (Pm % 256 == 0 && Pn % 256 == 0) return 42;
-  // (6, 1) for P = 384 (K = 181) is built and correct but measured SLOWER than the 128 x 128 3 x bf16 kernel at that width
-  // (0.609 against 0.578 ms, profiles/r03_gemm_x2_tn_shapes.txt; (7, 1) at P = 448: 0.497 against 0.858): off unless
-  // WIRE_X2_TN61=1
-  static const int tn61 = x2_env("WIRE_X2_TN61", 0);
-  if (Pm == 384 && tn61) return 61;
+  if (Pm == 384) return 61;
   if (Pm == 448) return 71;
   return 0;
 }
 bool gemmx2_tn_applies(int Pm, int Pn) { return x2_tn_shape(Pm, Pn) != 0; }
-// row splits that fill the 256 CUs with one workgroup each
+// Row splits that fill the chip with ONE workgroup per CU.  Blocks are dealt round-robin over the 8 XCDs and split s runs
+// its tiles on XCD s % 8, so an XCD receives tiles * ceil(splits / 8) workgroups and has 32 CUs: one more than 32 and a CU
+// runs two workgroups back to back -- the launch takes twice as long.  (Measured: 3 tiles x 84 splits = 33 workgroups on four
+// XCDs: 0.609 ms, waves alive 0.29 ms, profiles/r03_tn61_pmc_summary.txt; 3 x 80: see profiles/r03_gemm_x2_tn_shapes.txt.)
 int gemmx2_tn_splits(int64_t n, int Pm, int Pn, int max_splits) {
   const int shp = x2_tn_shape(Pm, Pn);
   if (!shp) return 0;
   const int TMf = 64 * (shp / 10), TNf = 128 * (shp % 10);
   const int tiles = (Pm / TMf) * ((Pn + TNf - 1) / TNf);
-  int s = tiles >= 256 ? 1 : 256 / tiles;
+  int s = tiles >= 32 ? 8 : 8 * (32 / tiles);
   int64_t by_rows = (n + 255) / 256;                     // at least 256 rows per split
   if (by_rows < 1) by_rows = 1;
   if (s > by_rows) s = (int)by_rows;
