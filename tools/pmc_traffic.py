@@ -44,7 +44,7 @@ def main():
                 a[0] += float(r.get("Counter_Value", 0) or 0)
                 a[1] += 1
                 names[k].add(re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", ""))
-    out = {"_comment": __doc__.split("\n\n")[1].replace("\n", " "), "csrc_sha": csrc_sha(), "traffic": {}, "mfma_busy": {},
+    out = {"_comment": " ".join(__doc__.split()), "csrc_sha": csrc_sha(), "traffic": {}, "mfma_busy": {},
            "kernels": {}, "launches_profiled": {}}
     for k in sorted(acc):
         c = {n: v[0] / v[1] for n, v in acc[k].items() if v[1]}

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
   const int l_st = l_hb * 1024 + l_rs * 32 + l_p * 8;     // + 2048 (block pair) + 256 (pass)
   const bool do_bias = (bslab != nullptr) && (tn == 0);
   // a Z tile that sticks out of the row (P = 448: the fourth 128-feature tile has 64): its loads stay inside the row
-  const bool z_edge = n_base + TN > Pn;
+  const bool z_edge = WN == 1 && n_base + TN > Pn;      // ((4, 2) only runs on widths that are multiples of 256)
 
   f32x4 acc[4][8];
 #pragma unroll
@@ -523,7 +523,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
 
   // three passes over the 8 Z blocks -- pair products of rows 0-15, pair products of rows 16-31, h h -- each holding the
   // G fragments of the wave's 4 blocks for ONE product kind: 16 + 4 fragment registers live beside the 128 accumulator and
-  // the staging registers (all three kinds at once: 48 + 12, and the allocator spills)
+  // the 32 - 44 staging registers.  (Both pair products in one pass, 32 + 8 fragment registers: 11 spilled registers at
+  // (4, 2) in this templated form -- the dedicated (4, 2) kernel it grew out of held them and ran 0.417 instead of 0.437 ms
+  // per launch at K = 256; all three kinds at once, 48 + 12, spill everywhere.  A spill reload waits in vmcnt order for the
+  // prefetched global loads, so no spill is tolerated here.)
   auto mfma_block = [&](const int buf) {
     const unsigned char* S = smem_t + buf * STAGE;
 #pragma unroll
