@@ -237,13 +237,16 @@ def extras(dev, lib):
                            hidden_layers=L, **wire_kw).to(dev)
     K = model._arch["width"]
     tr = FusedTrainer(model, (SIDE, SIDE), torch.zeros(SIDE * SIDE, O), lr=5e-3)
-    tr.render()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5):
+    for _ in range(2):
         tr.render()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 5
+    dt = float("inf")
+    for _ in range(3):                                   # best of 3 x 5 renders (tools/forward_only.py)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            tr.render()
+        torch.cuda.synchronize()
+        dt = min(dt, (time.perf_counter() - t0) / 5)
     Ff = 8 * K * K * L + 2 * D * K + 4 * K * O
     res["forward_only_k256_literal"] = {"samples_per_s": SIDE * SIDE / dt, "K": K,
                                         "frac_of_fp32_mfma_peak": SIDE * SIDE / dt * Ff / 1e12 / PEAK_FP32_MFMA_TFLOPS}

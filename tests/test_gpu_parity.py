@@ -657,12 +657,14 @@ def test_super_resolution_step_matches_oracle(H, W, scale):
 
 def test_random_shapes_against_oracle():
     """tools/fuzz_shapes.py: wire nets of random width / depth / D / O on random row counts, forward and all
-    gradients within 4 x the fp32 reference arithmetic's own error against fp64 (60 cases ran clean by hand;
-    16 here)."""
+    gradients against fp64 relative to the fp32 reference arithmetic's own error.  These are a few hundred rows of
+    shallow random nets, where err_ref is one noisy draw of ~1e-6: the worst ratio measured over 60 + 16 cases is 2.48
+    (profiles/r02_parity_ratios.txt), so the bound is that measured worst + a 20 % margin -- named as such, it is NOT
+    the protocol's 2 x, which the bench-size step tests (tests/test_gpu_timed_kernels.py) hold."""
     import importlib
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     fz = importlib.import_module("fuzz_shapes")
-    assert fz.main(16, 11) < 4.5
+    assert fz.main(16, 11) < 3.0
 
 
 def test_wire2d_per_layer_identical_inputs():

@@ -519,3 +519,51 @@ def test_first_layer_sums_in_epilogue_agree_with_separate_pass(nonlin):
     assert np.abs(a[:n0]).max() > 0
     assert relmax(b[:n0], a[:n0]) <= 5e-6
     assert np.array_equal(a[n0:], b[n0:])              # every other gradient is untouched by the knob
+
+
+def test_wide_offsets_beyond_4gib_on_the_32x32_kernels():
+    """the 32 x 32 x 16 epilogues (wire_gemm_epi.h) switch to 64-bit offsets (`ep.wide`) once a buffer
+    passes M * ld * 4 >= 4 GiB -- 2^21 rows of a 256-complex layer.  With the 16 x 16 x 32 editions switched off
+    ("x3_h16" = 0) a hidden ComplexGaborLayer (modules/wire.py:88-93) runs those kernels on 2^21 + 4133 rows: forward
+    and input gradient on rows sampled across the whole range (the last ones lie beyond the 4 GiB mark) against the fp64
+    oracle -- rows are independent --, weight / bias gradient against the default kernels on the same inputs."""
+    from wire_amd import _lib
+    om, sc = 20.0, 30.0
+    model = _wire_model(1, om, sc)
+    P64 = wo.cast_params(params_np(model), True)
+    W, b = P64["net.1.linear.weight"], P64["net.1.linear.bias"]
+    n = (1 << 21) + 4133
+    assert n * 512 * 4 >= 1 << 32
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = (0.3 * torch.randn(n, 256, 2, generator=g, device=DEV))
+    x = torch.view_as_complex(x).requires_grad_(True)
+    gout = torch.view_as_complex(torch.randn(n, 256, 2, generator=g, device=DEV))
+    L = _lib.lib()
+    res = {}
+    for h16 in (0, 15):
+        _lib.check(L.wire_tune_set(b"x3_h16", h16))
+        _lib.check(L.wire_tune_set(b"split_f16", 0))      # (the 2 x fp16 path needs the 16 x 16 x 32 kernels anyway)
+        try:
+            model.zero_grad()
+            x.grad = None
+            out = model.net[1](x)
+            out.backward(gout)
+            torch.cuda.synchronize()
+            rows = torch.cat([torch.arange(0, n, 104729), torch.arange(n - 300, n)]).to(DEV)
+            res[h16] = (out.detach()[rows].cpu().numpy(), x.grad[rows].cpu().numpy(),
+                        model.net[1].linear.weight.grad.cpu().numpy().copy(),
+                        model.net[1].linear.bias.grad.cpu().numpy().copy())
+            del out
+        finally:
+            _lib.check(L.wire_tune_set(b"x3_h16", 15))
+            _lib.check(L.wire_tune_set(b"split_f16", 1))
+    rows = torch.cat([torch.arange(0, n, 104729), torch.arange(n - 300, n)])
+    xs = x.detach()[rows.to(DEV)].cpu().numpy().astype(np.complex128)
+    gs = gout[rows.to(DEV)].cpu().numpy().astype(np.complex128)
+    lin64 = xs @ W.T + b
+    out64 = wo.gabor_act(lin64, om, sc)
+    gl = wo.gabor_act_grad(gs, lin64, out64, om, sc)
+    o32, gx32, gW32, gb32 = res[0]
+    assert relmax(o32, out64) <= 1e-5
+    assert relmax(gx32, gl @ np.conj(W)) <= 2e-5
+    assert relmax(gW32, res[15][2]) <= 2e-5 and relmax(gb32, res[15][3]) <= 2e-5
