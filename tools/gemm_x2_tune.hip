@@ -102,6 +102,15 @@ int main(int argc, char** argv) {
     size_t bad = 0;
     for (size_t i = 0; i < ref.size(); ++i) bad += memcmp(&ref[i], &got[i], 4) != 0;
     printf("   A via registers vs A via LDS: %zu of %zu words differ\n", bad, ref.size());
+    // 128-row tiles (3 workgroups per CU): the same arithmetic per element -> the same bits
+    gemmx2h_tune_set("x2_rows128", 1);
+    CK(hipMemset(r0, 0xff, (size_t)Nc * P * 4));
+    ep.o0 = r0; CK(launch_gemmx2h_nt(0, EPI_STORE, A, P, Bx2, Nc, P, P, ep));
+    gemmx2h_tune_set("x2_rows128", 0);
+    CK(hipMemcpy(ref.data(), r0, ref.size() * 4, hipMemcpyDeviceToHost));
+    bad = 0;
+    for (size_t i = 0; i < ref.size(); ++i) bad += memcmp(&ref[i], &got[i], 4) != 0;
+    printf("   128-row tiles vs 256-row tiles: %zu of %zu words differ\n", bad, ref.size());
   }
   // gabor forward epilogue + maximum slots of its output
   {
@@ -131,6 +140,8 @@ int main(int argc, char** argv) {
       {"x3h gabor_bwd recompute", 3, EPI_GABOR_BWD, 1, 0}, {"x2h gabor_bwd recompute (LDS)", 2, EPI_GABOR_BWD, 1, 0},
       {"x2h gabor_bwd recompute (regs)", 2, EPI_GABOR_BWD, 1, 1},
       {"x2h gabor_fwd no out (LDS)", 2, EPI_GABOR_FWD, 2, 0}, {"x2h gabor_fwd no out (regs)", 2, EPI_GABOR_FWD, 2, 1},
+      {"x2h store (128-row tiles)", 2, EPI_STORE, 0, 101}, {"x2h gabor_fwd (128-row tiles)", 2, EPI_GABOR_FWD, 0, 101},
+      {"x2h gabor_bwd rec (128-row tiles)", 2, EPI_GABOR_BWD, 1, 101}, {"x2h fwd no out (128-row tiles)", 2, EPI_GABOR_FWD, 2, 101},
       // ablation (results wrong): every row of A is row 0 -> all A loads hit the caches
       {"x2h store (LDS), A cached [abl]", 2, EPI_STORE, 0, 10}, {"x2h store (regs), A cached [abl]", 2, EPI_STORE, 0, 11},
   };
@@ -144,7 +155,8 @@ int main(int argc, char** argv) {
       ep.recompute_out = V.recompute == 1;
       ep.amax_a = slots; ep.amax_b = slots + 64; ep.amax_out = slots + 192;
       gemmx2h_tune_set("x2_amode", V.amode % 10);
-      const int lda = V.amode >= 10 ? 0 : P;
+      gemmx2h_tune_set("x2_rows128", V.amode >= 100 ? 1 : 0);
+      const int lda = (V.amode >= 10 && V.amode < 100) ? 0 : P;
       CK(hipEventRecord(e0, 0));
       for (int q = 0; q < 4; ++q) {
         if (V.fam == 3) CK(launch_gemmx3_nt(0, V.epi, A, P, Bx3, N, P, P, ep));

@@ -38,15 +38,17 @@ WIRE_DEVINL void h_amax4(float& m, const f32x4& v) {
                                          __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))));
 }
 
-template <int EPI, bool X2 = false>
-WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const int M, const int m_w, const int n_w,
+// NRB = 16-row blocks of the wave's tile (4: 64 rows per wave, 256-row workgroup tiles; 2: 32 rows per wave, 128-row tiles
+// -- not with the first-layer sums (cr_partial), whose per-tile layout is that of the 256-row tile)
+template <int EPI, bool X2 = false, int NRB = 4>
+WIRE_DEVINL void h_epilogue(f32x4 (&acc)[NRB][8], const GemmEpiParams& ep, const int M, const int m_w, const int n_w,
                             const int Nc, const int lane, unsigned char* lds, const int wave, const int rt,
                             const float acc_scale = 1.f) {
   const int rr = lane & 7, ch = (lane >> 3) & 1, g = lane >> 4;
   float amx = 0.f;
   if constexpr (X2) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NRB; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -59,7 +61,7 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
       const int col = n_w + 32 * sp + cq;
       if (n_w + 32 * sp >= Nc) continue;
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
+      for (int rb = 0; rb < NRB; ++rb) {
         f32x4 xp, yp;
         h_pair_rows(acc[rb][2 * sp], acc[rb][2 * sp + 1], xp, yp);
         const int row = m_w + 16 * rb + rr;
@@ -75,7 +77,7 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
       const int col = n_w + 32 * sp + cq;
       const f32x4 bv = *reinterpret_cast<const f32x4*>(ep.bias + col);
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
+      for (int rb = 0; rb < NRB; ++rb) {
         f32x4 a2[2];
         h_pair_rows(acc[rb][2 * sp], acc[rb][2 * sp + 1], a2[0], a2[1]);
 #pragma unroll
@@ -110,7 +112,7 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
 #pragma unroll
         for (int d = 0; d < 5; ++d) crs[q][d] = 0.f;
 #pragma unroll
-      for (int rp = 0; rp < 4; rp += 2) {
+      for (int rp = 0; rp < NRB; rp += 2) {
         f32x4 lv[4], ov[4], a2[4];
 #pragma unroll
         for (int r2 = 0; r2 < 2; ++r2) {
@@ -191,7 +193,7 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
 #pragma unroll
     for (int k = 0; k < 4; ++k) bv[k] = *reinterpret_cast<const f32x4*>(ep.bias + n_w + 32 * k + cq);
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
+    for (int rb = 0; rb < NRB; ++rb) {
       f32x4 part[4][2];
 #pragma unroll
       for (int k = 0; k < 4; ++k) h_pair_rows(acc[rb][2 * k], acc[rb][2 * k + 1], part[k][0], part[k][1]);
@@ -262,7 +264,7 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
         }
       }
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
+      for (int rb = 0; rb < NRB; ++rb) {
         f32x4 are[2], aim[2];
         h_pair_rows(acc[rb][4 * G], acc[rb][4 * G + 1], are[0], are[1]);
         h_pair_rows(acc[rb][4 * G + 2], acc[rb][4 * G + 3], aim[0], aim[1]);
@@ -419,7 +421,7 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[4][8], const GemmEpiParams& ep, const i
         }
       }
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
+      for (int rb = 0; rb < NRB; ++rb) {
         f32x4 are[2], aim[2];                                     // [0]: rows 0-7 of the block, [1]: rows 8-15
         h_pair_rows(acc[rb][4 * G], acc[rb][4 * G + 1], are[0], are[1]);
         h_pair_rows(acc[rb][4 * G + 2], acc[rb][4 * G + 3], aim[0], aim[1]);

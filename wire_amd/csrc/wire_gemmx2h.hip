@@ -142,11 +142,16 @@ hipError_t launch_x2_split_b_batch(hipStream_t s, const X2SplitBatch& sb, int nb
 // AMODE 0: A through LDS as described above.  AMODE 1: A straight from global memory into the fragment registers of the
 // NEXT stage (8 global_load_dwordx4 per lane and stage, in flight under the MFMAs of the current one): no LDS-DMA pieces,
 // no LDS reads and no wait for them at the top of a stage for A; LDS holds the weight stages only (32 KB).
-template <int EPI, int AMODE>
-__global__ __launch_bounds__(256, 2) void gemmx2h_nt_kernel(const float* __restrict__ A, int lda,
+// NRB = 16-row blocks per wave: 4 -> 256 x 128 tile, 128 accumulator registers, 2 workgroups per CU; 2 -> 128 x 128 tile, 64
+// accumulator registers, <= 168 registers in all: THREE workgroups per CU (AMODE 1 only: LDS holds the weight stages alone).
+template <int EPI, int AMODE, int NRB>
+__global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(const float* __restrict__ A, int lda,
                                                             const unsigned short* __restrict__ Bx2, int M, int Nc,
                                                             int Kd, int tiles_m, int tiles_n, GemmEpiParams ep) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[X2_ABYTES + 2 * X2_BSTAGE];   // (AMODE 1: the A part only serves the epilogues' reductions)
+  static_assert(NRB == 4 || AMODE == 1, "the 128-row tile loads A straight into registers");
+  constexpr int A_LDS = NRB == 4 ? X2_ABYTES : 0;      // (AMODE 1 at NRB 4: this part only serves the epilogues' reductions)
+  constexpr int TBM = 64 * NRB;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[A_LDS + 2 * X2_BSTAGE];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void gemmx2h_nt_kernel(const float* __restr
   const int ct = idx % tiles_n;
   const int rt = (idx / tiles_n) * 8 + xcd;
   if (rt >= tiles_m) return;
-  const int m_base = rt * X2_TBM, n_base = ct * X2_TBN;
+  const int m_base = rt * TBM, n_base = ct * X2_TBN;
   const int nk = Kd / X2_BK;
 
   // operand scales from the producers' maxima (uniform; a kernel boundary lies between the producers and this read)
@@ -167,12 +172,12 @@ __global__ __launch_bounds__(256, 2) void gemmx2h_nt_kernel(const float* __restr
   // ---- DMA plan.  A: this wave's own 64 rows, 8 pieces of (16 rows x 64 bytes) per stage -- block rb, k half p: lane =
   // (k slot inside the half, 16-byte half of the slot's 32 bytes, row) lands at [k slot][half][row][16 B] of the block,
   // the order the fragment reads below walk.  Offsets are relative to the tile's first row (32-bit).
-  unsigned a_off[4];
+  unsigned a_off[NRB];
   {
     const int r = lane & 15, hq = (lane >> 4) & 1, ksl = lane >> 5;
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-      int row = m_base + wave * 64 + rb * 16 + r;
+    for (int rb = 0; rb < NRB; ++rb) {
+      int row = m_base + wave * (16 * NRB) + rb * 16 + r;
       row = row < M ? row : M - 1;
       a_off[rb] = (unsigned)(row - m_base) * (unsigned)lda * 4u + (unsigned)(ksl * 32 + hq * 16);
     }
@@ -183,21 +188,21 @@ __global__ __launch_bounds__(256, 2) void gemmx2h_nt_kernel(const float* __restr
   const unsigned b_off = (unsigned)(wave * 1024 + lane * 16);
   unsigned char* const a_lds = smem + wave * X2_AWAVE;
   // AMODE 1: lane (row r = lane & 15, k slot ks = lane >> 4) loads its own 32 bytes of every block
-  unsigned g_off[4];
+  unsigned g_off[NRB];
   {
     const int r = lane & 15, ks = lane >> 4;
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-      int row = m_base + wave * 64 + rb * 16 + r;
+    for (int rb = 0; rb < NRB; ++rb) {
+      int row = m_base + wave * (16 * NRB) + rb * 16 + r;
       row = row < M ? row : M - 1;
       g_off[rb] = (unsigned)(row - m_base) * (unsigned)lda * 4u + (unsigned)(ks * 32);
     }
   }
-  f32x4 araw[4][2];
+  f32x4 araw[NRB][2];
   auto aload = [&](int kt) {
     const char* ab = a_tile + (size_t)kt * (X2_BK * 4);
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
+    for (int rb = 0; rb < NRB; ++rb) {
       araw[rb][0] = *reinterpret_cast<const f32x4*>(ab + g_off[rb]);
       araw[rb][1] = *reinterpret_cast<const f32x4*>(ab + g_off[rb] + 16);
     }
@@ -206,27 +211,27 @@ __global__ __launch_bounds__(256, 2) void gemmx2h_nt_kernel(const float* __restr
     const char* ab = a_tile + (size_t)kt * (X2_BK * 4);
     if constexpr (AMODE == 0) {
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
+      for (int rb = 0; rb < NRB; ++rb) {
         x2_dma16(ab + a_off[rb], a_lds + rb * 2048);
         x2_dma16(ab + a_off[rb] + 64, a_lds + rb * 2048 + 1024);
       }
     }
     const char* bb = b_tile + (size_t)kt * X2_BSTAGE;
-    unsigned char* S = smem + X2_ABYTES + buf * X2_BSTAGE + wave * 1024;
+    unsigned char* S = smem + A_LDS + buf * X2_BSTAGE + wave * 1024;
 #pragma unroll
     for (int j = 0; j < 4; ++j) x2_dma16(bb + b_off + j * 4096, S + j * 4096);
   };
 
-  f32x4 acc[4][8];
+  f32x4 acc[NRB][8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NRB; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment addresses: A block rb: lane (row r = lane & 15, k slot ks = lane >> 4) reads its 32 bytes as two 16-byte
   // pieces at [ks][0][r], [ks][1][r]; B block cb of a plane: lane * 16
   const int a_rd = wave * X2_AWAVE + (lane >> 4) * 512 + (lane & 15) * 16;
-  const int b_rd = X2_ABYTES + lane * 16;
+  const int b_rd = A_LDS + lane * 16;
   // the last column tile of a width that is no multiple of 128 (K = 212: 448) has 64 columns: skip the idle half
   const bool half_tile = Nc - n_base <= 64;
 
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void gemmx2h_nt_kernel(const float* __restr
   for (int kt = 0; kt < nk; ++kt) {
     if constexpr (AMODE == 0) {
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
+      for (int rb = 0; rb < NRB; ++rb) {
         araw[rb][0] = *reinterpret_cast<const f32x4*>(smem + a_rd + rb * 2048);
         araw[rb][1] = *reinterpret_cast<const f32x4*>(smem + a_rd + rb * 2048 + 256);
       }
@@ -249,9 +254,9 @@ __global__ __launch_bounds__(256, 2) void gemmx2h_nt_kernel(const float* __restr
       if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    f16x8 ah[4], al[4];
+    f16x8 ah[NRB], al[NRB];
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
+    for (int rb = 0; rb < NRB; ++rb) {
       unsigned H[4], L[4];
       x2_split2(araw[rb][0][0], araw[rb][0][1], s_a, H[0], L[0]);
       x2_split2(araw[rb][0][2], araw[rb][0][3], s_a, H[1], L[1]);
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void gemmx2h_nt_kernel(const float* __restr
         bl[cq] = *reinterpret_cast<const f16x8*>(S + X2_BPLANE + (4 * hb + cq) * 1024);
       }
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
+      for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
         for (int cq = 0; cq < 4; ++cq) {
           // small terms first; operands swapped (weights first): the block comes out transposed, four consecutive
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void gemmx2h_nt_kernel(const float* __restr
     __builtin_amdgcn_sched_barrier(0);
     buf ^= 1;
   }
-  h_epilogue<EPI, true>(acc, ep, M, m_base + wave * 64, n_base, Nc, lane, smem, wave, rt, inv_a * inv_b);
+  h_epilogue<EPI, true, NRB>(acc, ep, M, m_base + wave * (16 * NRB), n_base, Nc, lane, smem, wave, rt, inv_a * inv_b);
 }
 
 static int x2_env(const char* name, int dflt) {
@@ -306,23 +311,35 @@ static int x2_env(const char* name, int dflt) {
 // cost of the HBM reads is not their latency -- with every A row served from cache the store form takes 0.347 ms, i.e. the
 // 0.54 GB of A cost 0.105 ms, what they cost at 5 TB/s beside a matrix pipe that shares the chip's power budget).
 static std::atomic<int> g_x2_amode{x2_env("WIRE_X2_AMODE", 1)};
+// 128-row tiles (3 workgroups per CU) for every epilogue but the first-layer data gradients, whose per-tile sums are laid
+// out for 256-row tiles.  "x2_rows128" / WIRE_X2_ROWS128.
+static std::atomic<int> g_x2_rows128{x2_env("WIRE_X2_ROWS128", 0)};
 int gemmx2h_tune_set(const char* key, int value) {
   if (!strcmp(key, "x2_amode") && (value == 0 || value == 1)) { g_x2_amode = value; return 0; }
+  if (!strcmp(key, "x2_rows128") && (value == 0 || value == 1)) { g_x2_rows128 = value; return 0; }
   return -1;
 }
+
 
 template <int EPI>
 static hipError_t launchx2h_t(hipStream_t s, const float* A, int lda, const unsigned short* Bx2, int64_t M, int Nc,
                               int Kd, const GemmEpiParams& ep) {
-  const int tiles_m = (int)((M + X2_TBM - 1) / X2_TBM);
+  const bool small = g_x2_rows128 != 0 && EPI != EPI_GABOR_BWD_FIRST && EPI != EPI_GABOR2D_BWD_FIRST && !ep.cr_partial;
+  const int tbm = small ? 128 : X2_TBM;
+  const int tiles_m = (int)((M + tbm - 1) / tbm);
   const int tiles_n = (Nc + X2_TBN - 1) / X2_TBN;
   const int tiles_m_pad = (tiles_m + 7) & ~7;
+  const dim3 grid((unsigned)(tiles_m_pad * tiles_n));
+  if constexpr (EPI != EPI_GABOR_BWD_FIRST && EPI != EPI_GABOR2D_BWD_FIRST) {
+    if (small) {
+      hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 1, 2>), grid, dim3(256), 0, s, A, lda, Bx2, (int)M, Nc, Kd, tiles_m, tiles_n, ep);
+      return hipGetLastError();
+    }
+  }
   if (g_x2_amode == 1)
-    hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 1>), dim3((unsigned)(tiles_m_pad * tiles_n)), dim3(256), 0, s, A, lda, Bx2,
-                       (int)M, Nc, Kd, tiles_m, tiles_n, ep);
+    hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 1, 4>), grid, dim3(256), 0, s, A, lda, Bx2, (int)M, Nc, Kd, tiles_m, tiles_n, ep);
   else
-    hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 0>), dim3((unsigned)(tiles_m_pad * tiles_n)), dim3(256), 0, s, A, lda, Bx2,
-                       (int)M, Nc, Kd, tiles_m, tiles_n, ep);
+    hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 0, 4>), grid, dim3(256), 0, s, A, lda, Bx2, (int)M, Nc, Kd, tiles_m, tiles_n, ep);
   return hipGetLastError();
 }
 
