@@ -169,6 +169,27 @@ int main(int argc, char** argv) {
       if (r > 0) { sum[v] += ms; if (ms < best[v]) best[v] = ms; }
     }
   }
+  // ---- does the 256 MiB Infinity Cache pay for a chunk-major schedule?  Two chained store GEMMs (A -> o0 -> o1), layer by
+  // layer over all rows against chunk by chunk (each chunk's o0 slice is consumed right after it was produced)
+  {
+    GemmEpiParams ep; ep.ld0 = P; ep.ld1 = P; ep.amax_a = slots; ep.amax_b = slots + 64;
+    gemmx2h_tune_set("x2_amode", 1); gemmx2h_tune_set("x2_rows128", 0);
+    for (int nchunk : {1, 4, 8, 16}) {
+      const int64_t rows = N / nchunk;
+      double tsum = 0;
+      for (int r = 0; r < rounds + 1; ++r) {
+        CK(hipEventRecord(e0, 0));
+        for (int c = 0; c < nchunk; ++c) {
+          ep.o0 = o0 + (size_t)c * rows * P; CK(launch_gemmx2h_nt(0, EPI_STORE, A + (size_t)c * rows * P, P, Bx2, rows, P, P, ep));
+          ep.o0 = o1 + (size_t)c * rows * P; CK(launch_gemmx2h_nt(0, EPI_STORE, o0 + (size_t)c * rows * P, P, Bx2, rows, P, P, ep));
+        }
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0) tsum += ms;
+      }
+      printf("  two chained store GEMMs, %2d row chunk(s) of %lld rows: %7.3f ms for both layers\n", nchunk, (long long)rows, tsum / rounds);
+    }
+  }
   // ---- weight gradient (TN): slab[s] = G^T Z over row splits, 3 x bf16 (gemmx3_tn16) against 2 x fp16 (gemmx2_tn16)
   if (gemmx2_tn_applies(P, P)) {
     const int S = gemmx3_tn_splits(N, P, P, 256), S2 = gemmx2_tn_splits(N, P, P, 256);
