@@ -125,22 +125,25 @@ def final_bias_within_ref(g, g64, err_y_ref, ymax, O, label, factor=2.0, floor=1
 
 
 def family_ctx(fam):
-    """Context manager selecting a GEMM family of libwire_hip ('x3' split-bf16 on the bf16 MFMA -- the default
-    and the one bench.py times --, '3m' / '4m' fp32 MFMA) and restoring the default afterwards."""
+    """Context manager selecting a GEMM family of libwire_hip -- 'x2': 2 x fp16 split on the f16 MFMA (the default at
+    >= 4096 rows and the one bench.py times), 'x3': 3 x bf16 split on the bf16 MFMA (round 2's default; what smaller
+    batches run), '3m' / '4m': fp32 MFMA -- and restoring the default afterwards."""
     import contextlib
     from wire_amd import _lib
 
     @contextlib.contextmanager
     def ctx():
         L = _lib.lib()
-        sb, c3 = {"x3": (1, 1), "3m": (0, 1), "4m": (0, 0)}[fam]
+        sb, c3, f16 = {"x2": (1, 1, 1), "x3": (1, 1, 0), "3m": (0, 1, 1), "4m": (0, 0, 1)}[fam]
         _lib.check(L.wire_tune_set(b"split_bf16", sb))
         _lib.check(L.wire_tune_set(b"complex_3m", c3))
+        _lib.check(L.wire_tune_set(b"split_f16", f16))
         try:
             yield L
         finally:
             _lib.check(L.wire_tune_set(b"split_bf16", 1))
             _lib.check(L.wire_tune_set(b"complex_3m", 1))
+            _lib.check(L.wire_tune_set(b"split_f16", 1))
     return ctx()
 
 

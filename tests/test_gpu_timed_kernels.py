@@ -1,8 +1,8 @@
 """Parity protocol of SURVEY.md section 7 ON THE KERNELS bench.py TIMES.
 
-bench.py's step runs ``gemmx3_nt<EPI, 4, 2>`` (256-row tiles, selected at M >= 4096, lean hardware-transcendental
-epilogues; at M >= 4096 their 16x16x32 edition ``gemmx3h_nt``), ``gemmx3_tn16`` with a 64-way row split, and
-``final_fused_kernel``.  The fixtures of
+bench.py's step runs ``gemmx2h_nt<EPI>`` (2 x fp16 split on the 16x16x32 f16 MFMA, 256-row tiles, selected at M >= 4096,
+lean hardware-transcendental epilogues; "split_f16" = 0: the 3 x bf16 ``gemmx3h_nt``), ``gemmx2_tn16`` with a 64-way row
+split, and ``final_fused_kernel``.  The fixtures of
 tests/golden hold <= 512 rows, which select the 128-row tiles.  Here every check runs at row counts and widths
 that select the timed code:
 
@@ -47,7 +47,7 @@ def _grid_rows(n):
 
 
 @pytest.mark.parametrize("cfg", list(CFGS))
-@pytest.mark.parametrize("fam", ["x3", "3m", "4m"])
+@pytest.mark.parametrize("fam", ["x2", "x3", "3m", "4m"])
 def test_gabor_layers_identical_inputs_at_timed_shape(fam, cfg):
     om, sc = CFGS[cfg]
     model = _wire_model(2, om, sc)
@@ -86,11 +86,12 @@ def test_gabor_layers_identical_inputs_at_timed_shape(fam, cfg):
 
 
 @pytest.mark.parametrize("n", [300, N_TALL, 16384 + 21])
-@pytest.mark.parametrize("tn16", [0, 1])
+@pytest.mark.parametrize("tn16", [0, 1, 2])
 def test_weight_gradient_kernels_vs_fp64(tn16, n):
-    """The two split-bf16 weight-gradient kernels (wire_gemmx3.hip: gemmx3_tn_kernel, 128 x 128 tiles on the
-    32x32x16 MFMA; gemmx3_tn16_kernel, 256 x 256 tiles on the 16x16x32 MFMA -- the one bench.py times, knob
-    "x3_tn16") on a hidden ComplexGaborLayer's backward (autograd of modules/wire.py:89): dW = g_lin^T conj(x),
+    """The weight-gradient kernels -- tn16 = 2: gemmx2_tn16_kernel (wire_gemmx2h.hip, 2 x fp16 split, the one bench.py
+    times; at n < 4096 the layer runs the 3 x bf16 kernels whatever the knob); 0 / 1 with "split_f16" = 0: the two
+    split-bf16 kernels (wire_gemmx3.hip: gemmx3_tn_kernel, 128 x 128 tiles on the 32x32x16 MFMA; gemmx3_tn16_kernel,
+    256 x 256 tiles on the 16x16x32 MFMA, knob "x3_tn16") -- on a hidden ComplexGaborLayer's backward (autograd of modules/wire.py:89): dW = g_lin^T conj(x),
     db = sum g_lin, at row counts with one row split, a ragged last stage and many splits."""
     from wire_amd import _lib
     om, sc = 20.0, 30.0
@@ -104,8 +105,9 @@ def test_weight_gradient_kernels_vs_fp64(tn16, n):
     out64 = wo.gabor_act(lin64, om, sc)
     gl = wo.gabor_act_grad(g.astype(np.complex128), lin64, out64, om, sc)
     L = _lib.lib()
-    assert L.wire_tune_get(b"x3_tn16") == 1              # the default is the timed kernel
-    _lib.check(L.wire_tune_set(b"x3_tn16", tn16))
+    assert L.wire_tune_get(b"x3_tn16") == 1 and L.wire_tune_get(b"split_f16") == 1    # the defaults
+    _lib.check(L.wire_tune_set(b"x3_tn16", 1 if tn16 == 2 else tn16))
+    _lib.check(L.wire_tune_set(b"split_f16", 1 if tn16 == 2 else 0))
     try:
         x = torch.tensor(x_np, device=DEV, requires_grad=True)
         model.zero_grad()
@@ -113,13 +115,14 @@ def test_weight_gradient_kernels_vs_fp64(tn16, n):
         torch.cuda.synchronize()
     finally:
         _lib.check(L.wire_tune_set(b"x3_tn16", 1))
+        _lib.check(L.wire_tune_set(b"split_f16", 1))
     lw = model.net[1].linear
     e_w = relmax(lw.weight.grad.cpu().numpy(), gl.T @ np.conj(x_np.astype(np.complex128)))
     e_b = relmax(lw.bias.grad.cpu().numpy(), gl.sum(0))
     assert max(e_w, e_b) <= 2e-5, f"tn16={tn16} n={n}: gW {e_w:.2e} gb {e_b:.2e}"
 
 
-@pytest.mark.parametrize("fam", ["x3", "4m"])
+@pytest.mark.parametrize("fam", ["x2", "x3", "4m"])
 def test_gabor_fwd_lin_out(fam):
     """wire_gabor_fwd's optional pre-activation output (SURVEY 8(b)(1) ``lin_out``): complex64 for a hidden layer,
     float32 for is_first."""
@@ -156,7 +159,7 @@ def test_gabor_fwd_lin_out(fam):
 
 
 @pytest.mark.parametrize("kind,om,sc", [("siren", 30.0, 10.0), ("gauss", 30.0, 10.0), ("relu", 30.0, 10.0)])
-@pytest.mark.parametrize("fam", ["x3", "4m"])
+@pytest.mark.parametrize("fam", ["x2", "x3", "4m"])
 def test_real_layers_identical_inputs_at_timed_shape(fam, kind, om, sc):
     """SineLayer / GaussLayer / ReLULayer (modules/siren.py:48-49, gauss.py:27-28, relu.py:28-29), K = 256,
     n = 4133: the layer GEMMs of BASELINE.json configs[4] on the family the sweep times."""
@@ -194,7 +197,7 @@ def test_real_layers_identical_inputs_at_timed_shape(fam, kind, om, sc):
     assert relmax(model.net[1].linear.bias.grad.cpu().numpy(), gl.sum(0)) <= 2e-5
 
 
-@pytest.mark.parametrize("fam", ["x3", "4m"])
+@pytest.mark.parametrize("fam", ["x2", "x3", "4m"])
 def test_wire2d_layer_at_timed_shape(fam):
     """ComplexGaborLayer2D (modules/wire2d.py:56-67), K2 = 128, n = 4133, against eager fp64 autograd of the
     oracle's restatement (oracle/torch_ref.gabor2d)."""
@@ -243,8 +246,16 @@ STEP_CASES = {
 }
 
 
+@pytest.mark.parametrize("case", ["img16k_baseline_w20_s30", "img262k_baseline_w20_s30", "vol16k_occupancy_3x300_w20_s10"])
+def test_fused_trainer_step_bf16x3_family_vs_fp64_oracle(case):
+    """The same check on the 3 x bf16 split family ("split_f16" = 0: round 2's default, still what `WIRE_SPLIT_F16=0`
+    selects at any batch size)."""
+    with family_ctx("x3"):
+        test_fused_trainer_step_gradients_vs_fp64_oracle(case, tag_prefix="x3 ")
+
+
 @pytest.mark.parametrize("case", list(STEP_CASES))
-def test_fused_trainer_step_gradients_vs_fp64_oracle(case):
+def test_fused_trainer_step_gradients_vs_fp64_oracle(case, tag_prefix=""):
     """One FusedTrainer.step (lr = 0, a random permutation of the whole grid as the batch -- wire_image_denoise.py:
     142-157, wire_occupancy.py:137-158) at the bench's architecture.  N = 16 384 and 262 144 rows run
     gemmx3h_nt, final_fused_kernel and the row-split gemmx3_tn16 exactly as bench.py does (the 3 x 300 case: gemmx3_tn).  Output, loss and
@@ -267,7 +278,7 @@ def test_fused_trainer_step_gradients_vs_fp64_oracle(case):
     tgt = target.numpy()[perm.numpy()]
     y64, l64, g64 = wire_oracle_grads_chunked(P, coords, tgt, Ln, om, om, sc, double=True)
     y32, l32, g32 = wire_oracle_grads_chunked(P, coords, tgt, Ln, om, om, sc, double=False)
-    tag = f"step[{case}]"
+    tag = f"{tag_prefix}step[{case}]"
     err_y_ref = relmax(y32, y64)
     within_ref(relmax(tr.rec.cpu().numpy()[perm.numpy()], y64), err_y_ref, tag + " y")
     assert abs(float(loss.item()) - l64) <= (2 * abs(l32 - l64) / l64 + 1e-5) * l64

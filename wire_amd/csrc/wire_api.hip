@@ -127,6 +127,7 @@ int wire_family_(int kind) {
   if (g_split_bf16) return 2;
   return (kind == WIRE_KIND_WIRE && g_complex_3m) ? 1 : 0;
 }
+int wire_split_f16_() { return g_split_f16; }   // wire_layer_api.hip
 extern "C" int wire_tune_get(const char* key) {
   if (!key) return fail(WIRE_ERR_ARG, "null key");
   if (!strcmp(key, "complex_3m")) return g_complex_3m;
@@ -278,7 +279,9 @@ ScratchLayout scratch_layout(const Plan& p, int64_t n) {
   const int64_t pn = p.first_gemm && p.Pin0 > p.P ? p.Pin0 : p.P;
   // slabs sized for the largest split count of the three GEMM families (flag-independent scratch size)
   // (the split-bf16 kernel may split finer: narrow nets have few tiles and would otherwise leave CUs idle)
-  const int s_x3 = gemmx3_tn_splits_max(n, p.Pl, (int)pn, 256), s_4m = gemm_tn_splits(n, p.Pl, (int)pn, 64);
+  const int s_x3k = gemmx3_tn_splits_max(n, p.Pl, (int)pn, 256), s_4m = gemm_tn_splits(n, p.Pl, (int)pn, 64);
+  const int s_x2 = gemmx2_tn_splits(n, p.Pl, (int)pn, 256);      // 0 when the 2 x fp16 kernel has no shape for the widths
+  const int s_x3 = s_x3k > s_x2 ? s_x3k : s_x2;                  // split-family slabs: room for either kernel's count
   const int s_max = s_x3 > s_4m ? s_x3 : s_4m;
   if (p.m3) {
     s.S = gemm3m_tn_splits(n, p.Kp, p.Kp, 64);

@@ -19,7 +19,11 @@ extern int wire_fail_(int code, const char* msg);   // wire_api.hip
 // The per-layer entry points run the SAME kernels as wire_mlp_fwd / wire_mlp_bwd, so the per-layer parity
 // tests (protocol step (i)) check the code the bench times.
 extern int wire_family_(int kind);
+extern int wire_split_f16_();       // wire_api.hip: the "split_f16" knob
 enum { FAM_4M = 0, FAM_3M = 1, FAM_X3 = 2 };
+#ifndef WIRE_AMAX_SLOTS
+#define WIRE_AMAX_SLOTS 64
+#endif
 
 namespace {
 inline int rup(int v, int m) { return (v + m - 1) / m * m; }
@@ -27,8 +31,15 @@ inline int64_t rup64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 struct LayerWs {
   int Pin, Pout, S;
-  int64_t xb, lin, out, gact, glin, gxb, gu, btf, btd, bias, slab, bslab, fpw, fpb, crp, wf, bfr, btf_x3, btd_x3, total;
+  int64_t xb, lin, out, gact, glin, gxb, gu, btf, btd, bias, slab, bslab, fpw, fpb, crp, wf, bfr, btf_x3, btd_x3, x2, total;
 };
+// 2 x fp16 family in the per-layer entry points (split_f16, batches the 16 x 16 x 32 kernels take): a region of the
+// workspace holds 4 maximum-slot sets (A operand, weights, G, Z) and the two split weight images.  The operand maxima of
+// the fused path come from the producers' epilogues; here the tensors arrive from the caller, so one reduction pass
+// (launch_amax) per operand precedes the GEMM.
+inline int64_t x2_region_floats(int Pout_g, int Pin) {
+  return 4 * WIRE_AMAX_SLOTS + gemmx2_b_image_floats(Pout_g, Pin) + gemmx2_b_image_floats(Pin, Pout_g);
+}
 // weight-gradient row splits of a family (the workspace is sized for the largest: its size must not depend on
 // the tuning flags)
 inline int layer_splits(int fam, int64_t n, int Pout, int Pin) {
@@ -47,7 +58,8 @@ LayerWs layer_ws(int64_t n, int in, int out) {
   int64_t slab_f = 0, bslab_f = 0;
   auto fit = [&](int Pm, int Pn) {
     for (int fam = FAM_4M; fam <= FAM_X3; ++fam) {
-      const int64_t S = fam == FAM_X3 ? gemmx3_tn_splits_max(n, Pm, Pn, 256) : layer_splits(fam, n, Pm, Pn);
+      int64_t S = fam == FAM_X3 ? gemmx3_tn_splits_max(n, Pm, Pn, 256) : layer_splits(fam, n, Pm, Pn);
+      if (fam == FAM_X3 && gemmx2_tn_splits(n, Pm, Pn, 256) > S) S = gemmx2_tn_splits(n, Pm, Pn, 256);
       const int64_t sl = fam == FAM_3M ? S * 3 * (Pm / 2) * (Pn / 2) : S * Pm * Pn;
       if (sl > slab_f) slab_f = sl;
       if (S * Pm > bslab_f) bslab_f = S * Pm;
@@ -76,6 +88,7 @@ LayerWs layer_ws(int64_t n, int in, int out) {
   w.bfr = take(64);
   w.btf_x3 = take(gemmx3_b_image_floats(w.Pout, w.Pin));
   w.btd_x3 = take(gemmx3_b_image_floats(w.Pin, w.Pout));
+  w.x2 = take(x2_region_floats(w.Pout, w.Pin));
   w.total = off;
   return w;
 }
@@ -84,6 +97,11 @@ LayerWs layer_ws(int64_t n, int in, int out) {
 // outputs; they differ in the weight image (pack_*) and in the slab format of the weight gradient.
 struct LayerGemm {
   int fam;
+  float* x2ws;       // x2_region_floats(...) of the workspace, or null: never the 2 x fp16 kernels
+  bool use_x2(int epi, int64_t n) const {
+    return fam == FAM_X3 && x2ws && wire_split_f16_() && gemmx3_nt_is_h16(epi, n);
+  }
+  unsigned* slots(int which) const { return reinterpret_cast<unsigned*>(x2ws) + which * WIRE_AMAX_SLOTS; }
   // weights: W_ + btf / btd hold the fp32 images of the family, btf_x3 / btd_x3 the split images
   hipError_t pack(hipStream_t s, int kind, const float* W, const float* b, const float* V, const float* c, int out,
                   int in, int Pout_g, int Pin, float* btf, float* btd, float* bias, float* btf_x3,
@@ -94,19 +112,59 @@ struct LayerGemm {
     if (e != hipSuccess || fam != FAM_X3) return e;
     e = launch_x3_split_b(s, btf, Pin, Pout_g, Pin, btf_x3);
     if (e != hipSuccess) return e;
-    return launch_x3_split_b(s, btd, Pout_g, Pin, Pout_g, btd_x3);
+    e = launch_x3_split_b(s, btd, Pout_g, Pin, Pout_g, btd_x3);
+    if (e != hipSuccess || !x2ws || !wire_split_f16_()) return e;
+    // 2 x fp16 images: max |weight| (the transposed image holds the same values), then both scaled splits
+    e = hipMemsetAsync(x2ws, 0, 4 * WIRE_AMAX_SLOTS * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    e = launch_amax(s, btf, (int64_t)Pout_g * Pin, slots(1));
+    if (e != hipSuccess) return e;
+    float* img_f = x2ws + 4 * WIRE_AMAX_SLOTS;
+    float* img_d = img_f + gemmx2_b_image_floats(Pout_g, Pin);
+    X2SplitBatch xf{}, xd{};
+    xf.src[0] = btf; xf.dst[0] = img_f; xf.slots[0] = slots(1);
+    xd.src[0] = btd; xd.dst[0] = img_d; xd.slots[0] = slots(1);
+    e = launch_x2_split_b_batch(s, xf, 1, Pin, Pout_g, Pin);
+    if (e != hipSuccess) return e;
+    return launch_x2_split_b_batch(s, xd, 1, Pout_g, Pin, Pout_g);
   }
   // C[n][Nc] = A[n][Kd] * image^T + epilogue; dgrad = true uses the transposed-conjugate image
   hipError_t nt(hipStream_t s, int epi, const float* A, int64_t n, int Nc, int Kd, bool dgrad, const float* btf,
                 const float* btd, const float* btf_x3, const float* btd_x3, const GemmEpiParams& ep) const {
+    if (use_x2(epi, n)) {
+      // forward: image [Nc = Pout_g][Kd = Pin]; data gradient: the transposed image [Nc = Pin][Kd = Pout_g]
+      const int Pout_g = dgrad ? Kd : Nc, Pin = dgrad ? Nc : Kd;
+      float* img_f = x2ws + 4 * WIRE_AMAX_SLOTS;
+      float* img_d = img_f + gemmx2_b_image_floats(Pout_g, Pin);
+      unsigned* sa = slots(dgrad ? 2 : 0);
+      hipError_t e = hipMemsetAsync(sa, 0, WIRE_AMAX_SLOTS * sizeof(unsigned), s);
+      if (e != hipSuccess) return e;
+      e = launch_amax(s, A, n * Kd, sa);
+      if (e != hipSuccess) return e;
+      GemmEpiParams e2 = ep;
+      e2.amax_a = sa; e2.amax_b = slots(1);
+      return launch_gemmx2h_nt(s, epi, A, Kd, dgrad ? img_d : img_f, n, Nc, Kd, e2);
+    }
     if (fam == FAM_X3) return launch_gemmx3_nt(s, epi, A, Kd, dgrad ? btd_x3 : btf_x3, n, Nc, Kd, ep);
     if (fam == FAM_3M) return launch_gemm3m_nt(s, epi, A, Kd, dgrad ? btd : btf, Kd, n, Nc / 2, Kd / 2, ep);
     return launch_gemm_nt(s, epi, A, Kd, dgrad ? btd : btf, Kd, n, Nc, Kd, ep);
   }
   hipError_t tn_reduce(hipStream_t s, int kind, const float* G, const float* Z, int64_t n, int Pm, int Pn, int out,
                        int in, float* slab, float* bslab, float* gW, float* gb, float* gV, float* gc) const {
-    const int S = layer_splits(fam, n, Pm, Pn);
     hipError_t e;
+    if (use_x2(EPI_STORE, n) && gemmx2_tn_applies(Pm, Pn)) {
+      const int S2 = gemmx2_tn_splits(n, Pm, Pn, 256);
+      e = hipMemsetAsync(slots(2), 0, 2 * WIRE_AMAX_SLOTS * sizeof(unsigned), s);       // G and Z
+      if (e != hipSuccess) return e;
+      e = launch_amax(s, G, n * Pm, slots(2));
+      if (e != hipSuccess) return e;
+      e = launch_amax(s, Z, n * Pn, slots(3));
+      if (e != hipSuccess) return e;
+      e = launch_gemmx2_tn(s, G, Pm, Z, Pn, n, Pm, Pn, S2, slab, bslab, slots(2), slots(3));
+      if (e != hipSuccess) return e;
+      return launch_wgrad_reduce(s, kind, slab, bslab, S2, out, in, Pm, Pn, gW, gb, gV, gc);
+    }
+    const int S = layer_splits(fam, n, Pm, Pn);
     if (fam == FAM_3M) {
       e = launch_gemm3m_tn(s, G, Pm, Z, Pn, n, Pm / 2, Pn / 2, S, slab, bslab);
       if (e != hipSuccess) return e;
@@ -143,7 +201,7 @@ static int layer_forward_ws(hipStream_t s, const LayerWs& w, float* W_, const vo
                           W_ + w.out));
     return WIRE_OK;
   }
-  const LayerGemm g{wire_family_(WIRE_KIND_WIRE)};
+  const LayerGemm g{wire_family_(WIRE_KIND_WIRE), W_ + w.x2};
   LCHK(launch_c64_to_blocked(s, (const float*)x, n, in, w.Pin, W_ + w.xb));
   LCHK(g.pack(s, NK_WIRE, (const float*)Wt, (const float*)b, nullptr, nullptr, out, in, w.Pout, w.Pin, W_ + w.btf,
               W_ + w.btd, W_ + w.bias, W_ + w.btf_x3, W_ + w.btd_x3));
@@ -202,7 +260,7 @@ extern "C" int wire_gabor_bwd(void* stream, const void* g_act, const void* x, co
   }
   LCHK(launch_gabor_bwd_point(s, W_ + w.gact, W_ + w.lin, W_ + w.out, n, w.Pout, omega0, scale0,
                               W_ + w.glin));
-  const LayerGemm g{wire_family_(WIRE_KIND_WIRE)};
+  const LayerGemm g{wire_family_(WIRE_KIND_WIRE), W_ + w.x2};
   if (g_x) {
     GemmEpiParams ep; ep.o0 = W_ + w.gxb; ep.ld0 = w.Pin; ep.ld1 = w.Pin;
     LCHK(g.nt(s, EPI_STORE, W_ + w.glin, n, w.Pin, w.Pout, true, W_ + w.btf, W_ + w.btd, W_ + w.btf_x3,
@@ -283,7 +341,7 @@ static int real_epi_fwd(int kind) {
 static int real_forward_ws(hipStream_t s, const LayerWs& w, float* W_, int kind, const void* x, const void* Wt,
                            const void* b, float omega0, float scale0, int64_t n, int in, int out, int Pin,
                            int Pout) {
-  const LayerGemm g{wire_family_(kind)};
+  const LayerGemm g{wire_family_(kind), W_ + w.x2};
   LCHK(launch_pad_rows(s, (const float*)x, n, in, Pin, W_ + w.xb));
   LCHK(g.pack(s, kind, (const float*)Wt, (const float*)b, nullptr, nullptr, out, in, Pout, Pin, W_ + w.btf,
               W_ + w.btd, W_ + w.bias, W_ + w.btf_x3, W_ + w.btd_x3));
@@ -330,7 +388,7 @@ extern "C" int wire_real_layer_bwd(void* stream, int kind, const float* g_act, c
   LCHK(launch_pad_rows(s, g_act, n, out_features, Pout, W_ + w.gact));
   LCHK(launch_real_act_bwd_point(s, kind, W_ + w.gact, W_ + w.lin, W_ + w.out, n, Pout, omega0, scale0,
                                  W_ + w.glin));
-  const LayerGemm g{wire_family_(kind)};
+  const LayerGemm g{wire_family_(kind), W_ + w.x2};
   if (g_x) {
     GemmEpiParams ep; ep.o0 = W_ + w.gxb; ep.ld0 = Pin; ep.ld1 = Pin;
     LCHK(g.nt(s, EPI_STORE, W_ + w.glin, n, Pin, Pout, true, W_ + w.btf, W_ + w.btd, W_ + w.btf_x3, W_ + w.btd_x3,
@@ -349,7 +407,7 @@ extern "C" int wire_real_layer_bwd(void* stream, int kind, const float* g_act, c
 namespace {
 struct Layer2dWs {
   int Pin, Pout, S, ldu;
-  int64_t xb, linsy, out, gact, glinsy, gxb, gup, btf, btd, bias, slab, bslab, crp, btf_x3, btd_x3, total;
+  int64_t xb, linsy, out, gact, glinsy, gxb, gup, btf, btd, bias, slab, bslab, crp, btf_x3, btd_x3, x2, total;
 };
 Layer2dWs layer2d_ws(int64_t n, int in, int out) {
   Layer2dWs w{};
@@ -375,6 +433,7 @@ Layer2dWs layer2d_ws(int64_t n, int in, int out) {
   w.crp = take((int64_t)(colreduce_blocks(n) + 32) * w.ldu * 5);
   w.btf_x3 = take(gemmx3_b_image_floats(2 * w.Pout, w.Pin));
   w.btd_x3 = take(gemmx3_b_image_floats(w.Pin, 2 * w.Pout));
+  w.x2 = take(x2_region_floats(2 * w.Pout, w.Pin));
   w.total = off;
   return w;
 }
@@ -390,7 +449,7 @@ int layer2d_forward_ws(hipStream_t s, const Layer2dWs& w, float* W_, const void*
                           want_lin ? W_ + w.linsy : nullptr, W_ + w.out));
     return WIRE_OK;
   }
-  const LayerGemm g{wire_family_(WIRE_KIND_WIRE2D)};
+  const LayerGemm g{wire_family_(WIRE_KIND_WIRE2D), W_ + w.x2};
   LCHK(launch_c64_to_blocked(s, (const float*)x, n, in, w.Pin, W_ + w.xb));
   LCHK(g.pack(s, NK_WIRE2D, (const float*)Wt, (const float*)b, (const float*)Vt, (const float*)c, out, in,
               2 * w.Pout, w.Pin, W_ + w.btf, W_ + w.btd, W_ + w.bias, W_ + w.btf_x3, W_ + w.btd_x3));
@@ -469,7 +528,7 @@ extern "C" int wire_gabor2d_bwd(void* stream, const void* g_act, const void* x, 
   }
   LCHK(launch_gabor2d_bwd_point(s, W_ + w.gact, W_ + w.linsy, W_ + w.out, n, w.Pout, omega0, scale0,
                                 W_ + w.glinsy));
-  const LayerGemm g{wire_family_(WIRE_KIND_WIRE2D)};
+  const LayerGemm g{wire_family_(WIRE_KIND_WIRE2D), W_ + w.x2};
   if (g_x) {
     GemmEpiParams ep; ep.o0 = W_ + w.gxb; ep.ld0 = w.Pin; ep.ld1 = w.Pin;
     LCHK(g.nt(s, EPI_STORE, W_ + w.glinsy, n, w.Pin, 2 * w.Pout, true, W_ + w.btf, W_ + w.btd, W_ + w.btf_x3,
