@@ -190,3 +190,33 @@ def test_trainable_gabor_gradients_closed_form():
 
 def lin_dtype(W):
     return np.complex128 if np.iscomplexobj(W) else np.float64
+
+
+def test_relu_forced_decisions_reduce_to_the_plain_oracle():
+    """oracle.realnet_backward(relu_masks=...) (the identical-decisions comparison of the relu step test): with the
+    oracle's own decisions (lin > 0) it IS the plain backward; with one decision flipped only that element's
+    contribution changes -- by exactly g_out z^T for the weight gradient of its layer."""
+    from _util import build_model, load_golden, meta, params_np
+    from oracle import wire_oracle as wo
+    rec = load_golden("small_relu")
+    m = meta(rec)
+    P = wo.cast_params(params_np(build_model(rec)), True)
+    c = rec["coords"].reshape(-1, m["D"]).astype(np.float64)
+    t = rec["target"].reshape(-1, m["O"]).astype(np.float64)
+    y, cache = wo.realnet_forward("relu", P, c, m["L"], m["om1"], m["om"], m["sc"], None, keep=True)
+    _, gy = wo.mse_loss_and_grad(y, t)
+    g0 = wo.realnet_backward("relu", P, cache, gy, m["L"], m["om1"], m["om"], m["sc"])
+    masks = [lin > 0 for lin in cache["lin"]]
+    g1 = wo.realnet_backward("relu", P, cache, gy, m["L"], m["om1"], m["om"], m["sc"], relu_masks=masks)
+    for k in g0:
+        np.testing.assert_array_equal(g0[k], g1[k])
+    masks[m["L"]] = masks[m["L"]].copy()
+    masks[m["L"]][3, 5] ^= True
+    g2 = wo.realnet_backward("relu", P, cache, gy, m["L"], m["om1"], m["om"], m["sc"], relu_masks=masks)
+    Wf = P[f"net.{m['L'] + 1}.weight"]
+    g_out = (gy @ Wf)[3, 5]
+    sign = 1.0 if masks[m["L"]][3, 5] else -1.0
+    d = g2[f"net.{m['L']}.linear.weight"] - g0[f"net.{m['L']}.linear.weight"]
+    expect = np.zeros_like(d)
+    expect[5, :] = sign * g_out * cache["out"][m["L"] - 1][3]
+    np.testing.assert_allclose(d, expect, atol=1e-15)
