@@ -111,6 +111,14 @@ int main(int argc, char** argv) {
     bad = 0;
     for (size_t i = 0; i < ref.size(); ++i) bad += memcmp(&ref[i], &got[i], 4) != 0;
     printf("   128-row tiles vs 256-row tiles: %zu of %zu words differ\n", bad, ref.size());
+    gemmx2h_tune_set("x2_rows128", 2);
+    CK(hipMemset(r0, 0xff, (size_t)Nc * P * 4));
+    ep.o0 = r0; CK(launch_gemmx2h_nt(0, EPI_STORE, A, P, Bx2, Nc, P, P, ep));
+    gemmx2h_tune_set("x2_rows128", 0);
+    CK(hipMemcpy(ref.data(), r0, ref.size() * 4, hipMemcpyDeviceToHost));
+    bad = 0;
+    for (size_t i = 0; i < ref.size(); ++i) bad += memcmp(&ref[i], &got[i], 4) != 0;
+    printf("   128-row tiles + 2-stage prefetch vs 256-row tiles: %zu of %zu words differ\n", bad, ref.size());
   }
   // gabor forward epilogue + maximum slots of its output
   {
@@ -142,6 +150,10 @@ int main(int argc, char** argv) {
       {"x2h gabor_fwd no out (LDS)", 2, EPI_GABOR_FWD, 2, 0}, {"x2h gabor_fwd no out (regs)", 2, EPI_GABOR_FWD, 2, 1},
       {"x2h store (128-row tiles)", 2, EPI_STORE, 0, 101}, {"x2h gabor_fwd (128-row tiles)", 2, EPI_GABOR_FWD, 0, 101},
       {"x2h gabor_bwd rec (128-row tiles)", 2, EPI_GABOR_BWD, 1, 101}, {"x2h fwd no out (128-row tiles)", 2, EPI_GABOR_FWD, 2, 101},
+      {"x2h store (128-row, prefetch 2)", 2, EPI_STORE, 0, 201}, {"x2h gabor_fwd (128-row, prefetch 2)", 2, EPI_GABOR_FWD, 0, 201},
+      {"x2h gabor_bwd rec (128-row, pf 2)", 2, EPI_GABOR_BWD, 1, 201}, {"x2h fwd no out (128-row, pf 2)", 2, EPI_GABOR_FWD, 2, 201},
+      // probe (results wrong): A addressed as if stored k-slab-major inside 256-row tiles (a stage = one contiguous 32 KB)
+      {"x2h store, tiled-A addressing [probe]", 2, EPI_STORE, 0, 1001}, {"x2h fwd no out, tiled-A [probe]", 2, EPI_GABOR_FWD, 2, 1001},
       // ablation (results wrong): every row of A is row 0 -> all A loads hit the caches
       {"x2h store (LDS), A cached [abl]", 2, EPI_STORE, 0, 10}, {"x2h store (regs), A cached [abl]", 2, EPI_STORE, 0, 11},
   };
@@ -154,8 +166,9 @@ int main(int argc, char** argv) {
       ep.omega = 20.f; ep.scale = 30.f; ep.kvalid = P / 2;
       ep.recompute_out = V.recompute == 1;
       ep.amax_a = slots; ep.amax_b = slots + 64; ep.amax_out = slots + 192;
+      ep.stagger = V.amode >= 1000 ? 777 : 0;
       gemmx2h_tune_set("x2_amode", V.amode % 10);
-      gemmx2h_tune_set("x2_rows128", V.amode >= 100 ? 1 : 0);
+      gemmx2h_tune_set("x2_rows128", V.amode >= 1000 ? 0 : (V.amode >= 200 ? 2 : (V.amode >= 100 ? 1 : 0)));
       const int lda = (V.amode >= 10 && V.amode < 100) ? 0 : P;
       CK(hipEventRecord(e0, 0));
       for (int q = 0; q < 4; ++q) {

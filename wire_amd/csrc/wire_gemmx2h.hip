@@ -144,14 +144,17 @@ hipError_t launch_x2_split_b_batch(hipStream_t s, const X2SplitBatch& sb, int nb
 // no LDS reads and no wait for them at the top of a stage for A; LDS holds the weight stages only (32 KB).
 // NRB = 16-row blocks per wave: 4 -> 256 x 128 tile, 128 accumulator registers, 2 workgroups per CU; 2 -> 128 x 128 tile, 64
 // accumulator registers, <= 168 registers in all: THREE workgroups per CU (AMODE 1 only: LDS holds the weight stages alone).
-template <int EPI, int AMODE, int NRB>
+// PFD = stages of prefetch distance: 1 -> the rows and weight pieces of stage kt + 1 go out during stage kt; 2 (NRB 2, AMODE 1
+// only: it needs a second set of raw-fragment registers and a third weight buffer) -> those of stage kt + 2.
+template <int EPI, int AMODE, int NRB, int PFD = 1>
 __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(const float* __restrict__ A, int lda,
                                                             const unsigned short* __restrict__ Bx2, int M, int Nc,
                                                             int Kd, int tiles_m, int tiles_n, GemmEpiParams ep) {
   static_assert(NRB == 4 || AMODE == 1, "the 128-row tile loads A straight into registers");
+  static_assert(PFD == 1 || (PFD == 2 && NRB == 2 && AMODE == 1), "two stages of prefetch: 128-row tile, A in registers");
   constexpr int A_LDS = NRB == 4 ? X2_ABYTES : 0;      // (AMODE 1 at NRB 4: this part only serves the epilogues' reductions)
   constexpr int TBM = 64 * NRB;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[A_LDS + 2 * X2_BSTAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[A_LDS + (PFD + 1) * X2_BSTAGE];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -196,11 +199,21 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
       int row = m_base + wave * (16 * NRB) + rb * 16 + r;
       row = row < M ? row : M - 1;
       g_off[rb] = (unsigned)(row - m_base) * (unsigned)lda * 4u + (unsigned)(ks * 32);
+#ifdef WIRE_X2_TILED_PROBE
+      // timing probe (results wrong): address A as if it were stored k-slab-major inside a 256-row tile --
+      // [stage][row][32 k] -- so that a workgroup stage reads one contiguous 32 KB block
+      if (ep.stagger == 777) g_off[rb] = (unsigned)(row - m_base) * 128u + (unsigned)(ks * 32);
+#endif
     }
   }
+#ifdef WIRE_X2_TILED_PROBE
+  const size_t a_step = ep.stagger == 777 ? (size_t)TBM * 128 : (size_t)(X2_BK * 4);
+#else
+  constexpr size_t a_step = X2_BK * 4;
+#endif
   f32x4 araw[NRB][2];
   auto aload = [&](int kt) {
-    const char* ab = a_tile + (size_t)kt * (X2_BK * 4);
+    const char* ab = a_tile + (size_t)kt * a_step;
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) {
       araw[rb][0] = *reinterpret_cast<const f32x4*>(ab + g_off[rb]);
@@ -234,6 +247,73 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
   const int b_rd = A_LDS + lane * 16;
   // the last column tile of a width that is no multiple of 128 (K = 212: 448) has 64 columns: skip the idle half
   const bool half_tile = Nc - n_base <= 64;
+
+  if constexpr (PFD == 2) {
+    // stages come in pairs (nk is even: Kd is a multiple of 64): the even stage of a pair lives in ar0, the odd one in ar1;
+    // weight stage kt in buffer kt % 3.  During stage kt the loads of stage kt + 2 go out; the wait at its end leaves exactly
+    // those (2 NRB + 4 = 8 memory operations) in flight and guarantees stage kt + 1's.
+    f32x4 ar1[NRB][2];
+    auto aload_to = [&](f32x4 (&dst)[NRB][2], int kt) {
+      const char* ab = a_tile + (size_t)kt * (X2_BK * 4);
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+        dst[rb][0] = *reinterpret_cast<const f32x4*>(ab + g_off[rb]);
+        dst[rb][1] = *reinterpret_cast<const f32x4*>(ab + g_off[rb] + 16);
+      }
+    };
+    auto half_stage = [&](f32x4 (&ar)[NRB][2], const int kt) {
+      f16x8 ah[NRB], al[NRB];
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+        unsigned H[4], L[4];
+        x2_split2(ar[rb][0][0], ar[rb][0][1], s_a, H[0], L[0]);
+        x2_split2(ar[rb][0][2], ar[rb][0][3], s_a, H[1], L[1]);
+        x2_split2(ar[rb][1][0], ar[rb][1][1], s_a, H[2], L[2]);
+        x2_split2(ar[rb][1][2], ar[rb][1][3], s_a, H[3], L[3]);
+        ah[rb] = __builtin_bit_cast(f16x8, x2u32x4{H[0], H[1], H[2], H[3]});
+        al[rb] = __builtin_bit_cast(f16x8, x2u32x4{L[0], L[1], L[2], L[3]});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const bool more = kt + 2 < nk;
+      if (more) { issue(kt + 2, (kt + 2) % 3); aload_to(ar, kt + 2); }
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned char* S = smem + b_rd + (kt % 3) * X2_BSTAGE;
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        if (hb == 1 && half_tile) break;
+        f16x8 bh[4], bl[4];
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) {
+          bh[cq] = *reinterpret_cast<const f16x8*>(S + (4 * hb + cq) * 1024);
+          bl[cq] = *reinterpret_cast<const f16x8*>(S + X2_BPLANE + (4 * hb + cq) * 1024);
+        }
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+          for (int cq = 0; cq < 4; ++cq) {
+            X2_MFMA(bl[cq], ah[rb], acc[rb][4 * hb + cq]);
+            X2_MFMA(bh[cq], al[rb], acc[rb][4 * hb + cq]);
+            X2_MFMA(bh[cq], ah[rb], acc[rb][4 * hb + cq]);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    static_assert(2 * NRB + 4 == 8, "the in-flight count of the end-of-stage wait");
+    issue(0, 0); aload_to(araw, 0);
+    issue(1, 1); aload_to(ar1, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; kt += 2) {
+      half_stage(araw, kt);
+      half_stage(ar1, kt + 1);
+    }
+    h_epilogue<EPI, true, NRB>(acc, ep, M, m_base + wave * (16 * NRB), n_base, Nc, lane, smem, wave, rt, inv_a * inv_b);
+    return;
+  }
 
   issue(0, 0);
   if constexpr (AMODE == 1) aload(0);
@@ -316,7 +396,7 @@ static std::atomic<int> g_x2_amode{x2_env("WIRE_X2_AMODE", 1)};
 static std::atomic<int> g_x2_rows128{x2_env("WIRE_X2_ROWS128", 0)};
 int gemmx2h_tune_set(const char* key, int value) {
   if (!strcmp(key, "x2_amode") && (value == 0 || value == 1)) { g_x2_amode = value; return 0; }
-  if (!strcmp(key, "x2_rows128") && (value == 0 || value == 1)) { g_x2_rows128 = value; return 0; }
+  if (!strcmp(key, "x2_rows128") && value >= 0 && value <= 2) { g_x2_rows128 = value; return 0; }
   return -1;
 }
 
@@ -324,18 +404,30 @@ int gemmx2h_tune_set(const char* key, int value) {
 template <int EPI>
 static hipError_t launchx2h_t(hipStream_t s, const float* A, int lda, const unsigned short* Bx2, int64_t M, int Nc,
                               int Kd, const GemmEpiParams& ep) {
+  // the 128-row editions (three workgroups per CU; optionally two stages of prefetch) are bit-identical and measured no
+  // faster (profiles/r03_gemm_x2_rows128.txt, r03_gemm_x2_prefetch2.txt): they are compiled into the harness build only
+#ifdef WIRE_X2_EXPERIMENTS
   const bool small = g_x2_rows128 != 0 && EPI != EPI_GABOR_BWD_FIRST && EPI != EPI_GABOR2D_BWD_FIRST && !ep.cr_partial;
+#else
+  const bool small = false;
+#endif
   const int tbm = small ? 128 : X2_TBM;
   const int tiles_m = (int)((M + tbm - 1) / tbm);
   const int tiles_n = (Nc + X2_TBN - 1) / X2_TBN;
   const int tiles_m_pad = (tiles_m + 7) & ~7;
   const dim3 grid((unsigned)(tiles_m_pad * tiles_n));
+#ifdef WIRE_X2_EXPERIMENTS
   if constexpr (EPI != EPI_GABOR_BWD_FIRST && EPI != EPI_GABOR2D_BWD_FIRST) {
+    if (small && g_x2_rows128 == 2 && (Kd & 63) == 0) {   // two stages of prefetch
+      hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 1, 2, 2>), grid, dim3(256), 0, s, A, lda, Bx2, (int)M, Nc, Kd, tiles_m, tiles_n, ep);
+      return hipGetLastError();
+    }
     if (small) {
       hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 1, 2>), grid, dim3(256), 0, s, A, lda, Bx2, (int)M, Nc, Kd, tiles_m, tiles_n, ep);
       return hipGetLastError();
     }
   }
+#endif
   if (g_x2_amode == 1)
     hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 1, 4>), grid, dim3(256), 0, s, A, lda, Bx2, (int)M, Nc, Kd, tiles_m, tiles_n, ep);
   else
