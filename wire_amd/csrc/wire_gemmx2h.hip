@@ -1,8 +1,8 @@
 // wire_gemmx2h.hip -- the layer GEMMs of the WIRE hot path as a TWO-way fp16 split on v_mfma_f32_16x16x32_f16.
 //
 // Arithmetic.  Every fp32 operand x is scaled by a power of two s (exact) and split into two fp16 terms,
-//     x s = h + l,   h = fp16(x s),  l = fp16(x s - h)        (round-to-nearest at both levels: |x s - h - l| <= 2^-24 |x s|,
-//                                                               one bit short of fp32's own 24)
+//     x s = h + l,   h = fp16(x s),  l = fp16(x s - h)        (round-to-nearest at both levels: |x s - h - l| <= 2^-23 |x s|
+//                                                               worst case -- 23 of fp32's 24 bits)
 // and a product is accumulated from the three partial products of weight >= 2^-12 of the leading one:
 //     a b  ~=  a_h b_l + a_l b_h + a_h b_h                     (dropped: a_l b_l <= 2^-22 |a b|)
 // Each partial product of two fp16 numbers is exact in fp32 and the MFMA accumulates in fp32.  Measured against fp64
@@ -23,14 +23,15 @@
 //  * 256 x 128 tile, 4 waves stacked in M (64 rows x 128 columns each), stages of 32 reduction indices: one MFMA
 //    covers the 32 k of a stage for ONE partial product -- three 16-cycle instructions per 16 x 16 block and stage,
 //    against six (as three paired ones per 16 k) in wire_gemmx3h.hip;
-//  * A: fp32 rows by LDS-DMA into a WAVE-PRIVATE, single-buffered 8 KB region (a wave reads its own 64 rows into
-//    registers at the top of a stage and then immediately refills the region for the next stage: no barrier, no second
-//    buffer), split in registers: 24 vector ops per 16-row block and stage (v_cvt_pk_f16_f32, v_fma_mix_f32), every
-//    lane productive -- 96 per wave and 32 k where the 3 x bf16 kernel spends 224;
+//  * A: every lane loads ITS fragment of the wave's 64 rows (row lane & 15, k slot lane >> 4: 32 bytes per 16-row block)
+//    straight from global memory into registers, one stage ahead (AMODE 1, default; AMODE 0: the same rows by LDS-DMA into a
+//    WAVE-PRIVATE, single-buffered 8 KB region that the wave reads at the top of a stage and refills right away -- no
+//    barrier, no second buffer; 3 % slower), and splits it in registers: 24 vector ops per 16-row block and stage
+//    (v_cvt_pk_f16_f32, v_fma_mix_f32), every lane productive -- 96 per wave and 32 k where the 3 x bf16 kernel spends 224;
 //  * B: the pre-split weight image (x2_split_b_kernel), two 8 KB planes per stage, double-buffered by LDS-DMA; the
 //    image is stored in FRAGMENT order [16-column block][k slot][column][8 k], so a fragment read is lane * 16 bytes
 //    (conflict-free, one address register) and a DMA piece is 1 KB as it lies;
-//  * LDS 64 KB -> 2 workgroups per CU; one s_barrier per stage;
+//  * LDS 64 KB (32 KB of weight stages + 32 KB the epilogue reductions use) -> 2 workgroups per CU; one s_barrier per stage;
 //  * epilogues: wire_gemmh_epi.h (shared with wire_gemmx3h.hip), with the scale and the maximum tracking.
 //
 // Replaces the ATen complex addmm / mm of modules/wire.py:89 and of its autograd backward (and the real addmm of
