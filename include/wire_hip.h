@@ -271,7 +271,8 @@ int wire_blocked_width(int K);   /* P = roundup(2K, 64) */
 /* Float offset of the stored activations out_l (n rows of P floats -- blocked planar for wire / wire2d, P = roundup(K, 64)
  * plain features for siren / gauss / relu; l = 0..hidden_layers) inside an act buffer that wire_mlp_fwd / wire_train_fwd_bwd
  * filled for n rows with save_for_bwd = 1: the per-layer activations of modules/utils.py:246-252 without re-running the
- * layers.  (With recompute_out the last hidden layer of a fused training step is not stored, except for relu.)          */
+ * layers.  (With recompute_out the last hidden layer of a fused training step is not stored, except for relu; with
+ * split_out the inner hidden layers 1 .. hidden_layers - 1 hold fp16 pairs, see the knob -- set it to 0 to read them.) */
 int64_t wire_act_out_offset(const wire_net_desc* d, int64_t n, int layer);
 int wire_c64_to_blocked(void* stream, const void* src, int64_t n, int K, float* dst);
 int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* dst);
@@ -286,6 +287,14 @@ int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* 
  *     the act / scratch / packed buffers) and read by the consumer kernel: no host round trip.  "x2_amode" (default 1):
  *     1 = the activation operand goes from global memory straight into fragment registers, 0 = through LDS.
  *     0 = the 3 x bf16 kernels below for every batch size.
+ * "split_out" (default 1; environment WIRE_SPLIT_OUT; with split_f16): the activations out_l of the INNER hidden layers
+ *     (1 <= l < hidden_layers) of a wire / wire2d / siren / gauss net are stored ALREADY SPLIT by the forward epilogue --
+ *     per 4 consecutive columns the 16 bytes [h h h h | l l l l] (fp16) instead of 4 floats, scale 2^(15 - e) from the
+ *     activation's a-priori bound exp(w0^2 / 4 s0^2) < 2^e (sine, Gaussian: 1) -- and read in that form by the next
+ *     layer's forward GEMM and by the weight-gradient GEMM, which then spend no vector instructions on the split.  Used
+ *     when the bound is <= 16 (w0 / s0 <= 3.33), recompute_out = 1 (nothing else reads out_l) and the widths have a
+ *     2 x fp16 weight-gradient shape; otherwise, and always for out_0, out_L and relu, activations stay fp32 with the
+ *     maximum tracked on the device.  Inside the act buffer only: every pointer of this interface still carries fp32.
  * "split_bf16" (default 1; environment WIRE_SPLIT_BF16): every GEMM of every net
  *     kind runs on the bf16 matrix cores with each fp32 operand split exactly into
  *     three bf16 terms (6 partial products, fp32 accumulate; fp32-accurate --
@@ -307,12 +316,12 @@ int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* 
  *     first layer's per-tile gradient sums itself instead of storing g_u for a separate reduction pass.
  * (The LDS-DMA 32x32x16 edition of round 2, "x3_glds", left the library: tools/wire_gemmx3g.hip, harness builds only.)
  * Buffer sizes (wire_packed_floats, wire_act_bytes, wire_bwd_scratch_bytes) and the layout of packed weights do not
- * depend on the knobs: wire_pack_params writes the weight image of every family, activations are fp32 blocked rows for
- * all of them.  The knobs must NOT change between a forward and the backward that consumes its activation buffer: the
+ * depend on the knobs: wire_pack_params writes the weight image of every family, activations are 4-byte-per-element
+ * blocked rows for all of them (fp32, or the fp16 pairs of split_out).  The knobs must NOT change between a forward and the backward that consumes its activation buffer: the
  * backward re-derives from them which kernel edition produced the activations (recompute_out: the lean forward form
  * whose bits it reproduces) and whether the forward filled the max-|value| slots the 2 x fp16 kernels scale by.     */
 int wire_tune_set(const char* key, int value);
-int wire_tune_get(const char* key);   /* "split_bf16" | "split_f16" | "complex_3m" | "x3_h16" | "x3_tn16" | "recompute_out" -> value; < 0 = error */
+int wire_tune_get(const char* key);   /* "split_bf16" | "split_f16" | "split_out" | "complex_3m" | "x3_h16" | "x3_tn16" | "recompute_out" -> value; < 0 = error */
 
 /* ---- profiling hooks (bench.py roofline) -------------------------------
  * When enabled, every launch of the hot kernels is bracketed by hipEvents on

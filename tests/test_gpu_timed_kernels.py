@@ -424,6 +424,51 @@ def test_recompute_out_is_bit_identical(nonlin):
     assert float(res[0][2].abs().max()) > 0
 
 
+@pytest.mark.parametrize("nonlin,hf", [("wire", 363), ("wire", 256), ("wire", 300), ("wire2d", 256), ("siren", 256),
+                                       ("gauss", 256)])
+def test_presplit_activations_agree_with_fp32_activations(nonlin, hf):
+    """Knob "split_out" (default 1; wire_api.hip: out_split_scale): with the 2 x fp16 kernels the forward epilogues store
+    out_l = exp(j w0 lin - s0^2 |lin|^2) (modules/wire.py:90-93; wire2d.py:62-67, siren.py:49, gauss.py:28) of the inner
+    hidden layers ALREADY SPLIT into fp16 pairs with a scale fixed from the activation's a-priori bound, and the next
+    forward GEMM and the weight-gradient GEMM read that format (K = 256: 256 x 256 weight-gradient tiles; hidden_features
+    256 / 300 -> K = 181 / 212: the 384- and 448-wide shapes).  The same two fp16 terms of every element as the in-kernel
+    split produces, up to the choice of the power-of-two scale: the step agrees to round-off, and the stored bytes differ."""
+    import ctypes as C
+    from wire_amd import _lib
+    from wire_amd.modules import models
+    from wire_amd.trainer import FusedTrainer
+    L = _lib.lib()
+    assert L.wire_tune_get(b"split_out") == 1
+    res = []
+    for knob in (0, 1):
+        _lib.check(L.wire_tune_set(b"split_out", knob))
+        try:
+            torch.manual_seed(3)
+            kw = dict(first_omega_0=20.0, hidden_omega_0=20.0, scale=30.0) if nonlin == "wire" else \
+                dict(first_omega_0=10.0, hidden_omega_0=10.0, scale=10.0) if nonlin in ("wire2d", "gauss") else \
+                dict(first_omega_0=30.0, hidden_omega_0=30.0)
+            model = models.get_INR(nonlin=nonlin, in_features=2, out_features=3, hidden_features=hf, hidden_layers=3,
+                                   **kw).to(DEV)
+            g = torch.Generator().manual_seed(5)
+            N = 96 * 67                                  # 6432 rows: ragged last 256-row tile
+            target = torch.rand(N, 3, generator=g)
+            perm = torch.randperm(N, generator=g).to(DEV)
+            tr = FusedTrainer(model, (96, 67), target, lr=0.0, keep_rec=True)
+            loss = tr.step(perm)
+            torch.cuda.synchronize()
+            off = _lib.check(L.wire_act_out_offset(C.byref(tr.desc), N, 1))
+            out1 = tr.act.view(torch.float32)[off:off + N * 64].clone()
+            res.append((loss.clone(), tr.rec.clone(), tr.flat_grad.clone(), out1))
+        finally:
+            _lib.check(L.wire_tune_set(b"split_out", 1))
+    assert not torch.equal(res[0][3], res[1][3]), "out_1 is stored in the same format with and without split_out"
+    assert abs(float(res[0][0]) - float(res[1][0])) <= 1e-6 * abs(float(res[0][0]))
+    e_y = relmax(res[1][1].cpu().numpy(), res[0][1].cpu().numpy())
+    e_g = relmax(res[1][2].cpu().numpy(), res[0][2].cpu().numpy())
+    print(f"split_out[{nonlin}, hidden_features {hf}]: rec {e_y:.2e}, flat gradient {e_g:.2e} (relative to the maximum)")
+    assert e_y <= 1e-6 and e_g <= 2e-6
+
+
 KIND_CASES = {
     # name: (get_INR kwargs, grid)  -- rows = a few 256-row blocks of the fused final stage plus a ragged one
     "wire": (dict(nonlin="wire", hidden_features=91, first_omega_0=7.0, hidden_omega_0=7.0, scale=6.0), (37, 29)),

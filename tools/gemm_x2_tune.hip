@@ -154,6 +154,9 @@ int main(int argc, char** argv) {
       {"x2h gabor_bwd rec (128-row, pf 2)", 2, EPI_GABOR_BWD, 1, 201}, {"x2h fwd no out (128-row, pf 2)", 2, EPI_GABOR_FWD, 2, 201},
       // probe (results wrong): A addressed as if stored k-slab-major inside 256-row tiles (a stage = one contiguous 32 KB)
       {"x2h store, tiled-A addressing [probe]", 2, EPI_STORE, 0, 1001}, {"x2h fwd no out, tiled-A [probe]", 2, EPI_GABOR_FWD, 2, 1001},
+      // probe (results wrong): the loaded 32 bytes used as the fp16 fragments themselves (a producer-side split)
+      {"x2h store, A pre-split [probe]", 2, EPI_STORE, 0, 2001}, {"x2h gabor_fwd, A pre-split [probe]", 2, EPI_GABOR_FWD, 0, 2001},
+      {"x2h fwd no out, A pre-split [probe]", 2, EPI_GABOR_FWD, 2, 2001}, {"x2h gabor_bwd rec, A pre-split [probe]", 2, EPI_GABOR_BWD, 1, 2001},
       // ablation (results wrong): every row of A is row 0 -> all A loads hit the caches
       {"x2h store (LDS), A cached [abl]", 2, EPI_STORE, 0, 10}, {"x2h store (regs), A cached [abl]", 2, EPI_STORE, 0, 11},
   };
@@ -166,7 +169,7 @@ int main(int argc, char** argv) {
       ep.omega = 20.f; ep.scale = 30.f; ep.kvalid = P / 2;
       ep.recompute_out = V.recompute == 1;
       ep.amax_a = slots; ep.amax_b = slots + 64; ep.amax_out = slots + 192;
-      ep.stagger = V.amode >= 1000 ? 777 : 0;
+      ep.stagger = V.amode >= 2000 ? 778 : (V.amode >= 1000 ? 777 : 0);
       gemmx2h_tune_set("x2_amode", V.amode % 10);
       gemmx2h_tune_set("x2_rows128", V.amode >= 1000 ? 0 : (V.amode >= 200 ? 2 : (V.amode >= 100 ? 1 : 0)));
       const int lda = (V.amode >= 10 && V.amode < 100) ? 0 : P;

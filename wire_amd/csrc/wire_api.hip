@@ -122,6 +122,10 @@ static std::atomic<int> g_split_bf16{env_flag("WIRE_SPLIT_BF16", 1)};
 // matrix-core products per fp32 product, operand scales from device-side maxima; needs split_bf16 and the 16 x 16 x 32
 // kernels (x3_h16) for the net kind, falls back to the 3 x bf16 kernels otherwise
 static std::atomic<int> g_split_f16{env_flag("WIRE_SPLIT_F16", 1)};
+// with split_f16: activations with an a-priori bound (Gabor, sine, Gaussian outputs) are stored ALREADY SPLIT into fp16
+// pairs by the epilogue that produces them (wire_dev.h: wire_store_out4), so the GEMMs that read them -- the next layer's
+// forward, the weight gradient -- spend no vector instructions on the split (out_split_scale below)
+static std::atomic<int> g_split_out{env_flag("WIRE_SPLIT_OUT", 1)};
 // family the flags select for a net kind (wire_layer_api.hip): 2 split-bf16, 1 complex 3M (wire only), 0 4M
 int wire_family_(int kind) {
   if (g_split_bf16) return 2;
@@ -132,6 +136,7 @@ extern "C" int wire_tune_get(const char* key) {
   if (!key) return fail(WIRE_ERR_ARG, "null key");
   if (!strcmp(key, "complex_3m")) return g_complex_3m;
   if (!strcmp(key, "split_bf16")) return g_split_bf16;
+  if (!strcmp(key, "split_out")) return g_split_out;
   if (!strcmp(key, "x3_h16")) return gemmx3h_mode();
   if (!strcmp(key, "x3_tn16")) return gemmx3_tn16_mode();
   if (!strcmp(key, "recompute_out")) return g_recompute_out;
@@ -145,6 +150,7 @@ extern "C" int wire_tune_set(const char* key, int value) {
   if (!strcmp(key, "recompute_out")) { g_recompute_out = value ? 1 : 0; return WIRE_OK; }
   if (!strcmp(key, "first_sums")) { g_first_sums = value ? 1 : 0; return WIRE_OK; }
   if (!strcmp(key, "split_f16")) { g_split_f16 = value ? 1 : 0; return WIRE_OK; }
+  if (!strcmp(key, "split_out")) { g_split_out = value ? 1 : 0; return WIRE_OK; }
   if (gemmx2h_tune_set(key, value) == 0) return WIRE_OK;
   if (gemm_tune_set(key, value) == 0) return WIRE_OK;
   if (gemmx3_tune_set(key, value) == 0) return WIRE_OK;
@@ -316,6 +322,30 @@ int epi_bwd(int kind);
 // kernel (M >= 4096, x3_h16 bits of the kind), whose epilogues track the maxima the next GEMM scales by
 bool use_x2(const Plan& p, int64_t n) {
   return p.x2 && p.L >= 1 && gemmx3_nt_is_h16(epi_fwd(p.kind), n) && gemmx3_nt_is_h16(epi_bwd(p.kind), n);
+}
+// Scale with which out_l of this call is stored pre-split (wire_dev.h: wire_store_out4), 0 = plain fp32.  Pre-split when
+//  * the call runs the 2 x fp16 kernels and every reader of out_l understands the format: the forward GEMM of layer l + 1
+//    (pre-split A edition), the weight-gradient GEMM of layer l + 1 (gemmx2_tn16, pre-split Z) and NOTHING else -- the
+//    data-gradient epilogue of layer l + 1 must evaluate act(lin_l) again rather than read out_l (recompute_out; sine needs
+//    no out), out_L feeds the final linear layer in fp32, relu's out carries its backward's sign decisions;
+//  * l >= 1 (out_0 comes from first_fwd_kernel);
+//  * max |out_l| has a bound that is known here AND is reached in practice, so that a scale fixed on the host wastes no
+//    fp16 range: sine and Gaussian <= 1; Gabor |exp(j w lin - s^2 |lin|^2)| = exp(-w v - s^2 (u^2 + v^2)) <= exp(w^2 / 4 s^2),
+//    attained at lin = -j w / 2 s^2 -- accepted up to 16 (w / s <= 3.33: every configuration of the reference's scripts;
+//    beyond it the maximum is tracked on the device as before).  bound < 2^e  ->  scale 2^(15 - e): |out| scale < 2^15.
+float out_split_scale(const Plan& p, int64_t n, int l) {
+  if (!g_split_out || l < 1 || l >= p.L || p.kind == WIRE_KIND_RELU) return 0.f;
+  if (!use_x2(p, n) || !gemmx2_tn_applies(p.Pl, p.P)) return 0.f;
+  if (!g_recompute_out && p.kind != WIRE_KIND_SIREN) return 0.f;
+  double bound = 1.0;
+  if (p.cplx) {
+    if (!(p.s > 0.f)) return 0.f;
+    const double r = (double)p.w / (2.0 * (double)p.s);
+    if (!(r * r <= 2.7725887)) return 0.f;                 // ln 16
+    bound = exp(r * r);
+  }
+  const int e = ilogb(bound) + 1;
+  return ldexpf(1.f, 15 - e);
 }
 int epi_fwd(int kind) {
   switch (kind) {
@@ -504,6 +534,10 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
     ProfScope ps(s, 0, 2.0 * n * p.Pl * p.P);
     if (x2) {
       ep.amax_a = amax + (l - 1) * WIRE_AMAX_SLOTS; ep.amax_b = wamax(l); ep.amax_out = amax + l * WIRE_AMAX_SLOTS;
+      // pre-split activations: out_{l-1} read as such, out_l written as such (its maximum slots stay zero: not read)
+      const float s_in = out_split_scale(p, n, l - 1), s_out = ep.o1 ? out_split_scale(p, n, l) : 0.f;
+      if (s_in != 0.f) ep.a_split_inv = 1.f / s_in;
+      if (s_out != 0.f) { ep.o1_split = s_out; ep.amax_out = nullptr; }
       HIPCHK(launch_gemmx2h_nt(s, epi_fwd(p.kind), out_l(l - 1), p.P, packed + p.off_fwd_x2[l], n, p.Pl, p.P, ep));
     } else if (p.m3)
       HIPCHK(launch_gemm3m_nt(s, EPI_GABOR_FWD, out_l(l - 1), p.P, packed + p.off_fwd_3m[l], p.P, n, p.Kp,
@@ -619,9 +653,12 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
       const int S = x2tn ? gemmx2_tn_splits(n, p.Pl, p.P, sc.S)
                          : (p.x3 ? gemmx3_tn_splits(n, p.Pl, p.P, sc.S) : gemm_tn_splits(n, p.Pl, p.P, sc.S));
       { ProfScope ps(s, 2, 2.0 * n * p.Pl * p.P);
-        if (x2tn)
+        if (x2tn) {
+          const float s_z = out_split_scale(p, n, l - 1);
           HIPCHK(launch_gemmx2_tn(s, gcur, p.Pl, out_l(l - 1), p.P, n, p.Pl, p.P, S, Sx + sc.slab, Sx + sc.bslab,
-                                  gamax + l * WIRE_AMAX_SLOTS, amax + (l - 1) * WIRE_AMAX_SLOTS));
+                                  gamax + l * WIRE_AMAX_SLOTS, amax + (l - 1) * WIRE_AMAX_SLOTS,
+                                  s_z != 0.f ? 1.f / s_z : 0.f));
+        }
         else if (p.x3)
           HIPCHK(launch_gemmx3_tn(s, gcur, p.Pl, out_l(l - 1), p.P, n, p.Pl, p.P, S, Sx + sc.slab,
                                   Sx + sc.bslab));

@@ -243,3 +243,36 @@ WIRE_DEVINL void wire_x2_scales(unsigned maxbits, float& s, float& inv) {
   s = __uint_as_float((unsigned)(268 - E) << 23);
   inv = __uint_as_float((unsigned)(E - 14) << 23);
 }
+
+// ---- the split itself ------------------------------------------------------------------------------
+typedef _Float16 wire_f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned wire_u32x4 __attribute__((ext_vector_type(4)));
+WIRE_DEVINL unsigned x2_cvt_pk(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wire_f16x2));   // v_cvt_pk_f16_f32 (round to nearest)
+}
+// (x0, x1) s = H + L in packed fp16 pairs (low half = first element): 6 vector ops
+WIRE_DEVINL void x2_split2(float x0, float x1, float s, unsigned& H, unsigned& L) {
+  H = x2_cvt_pk(x0 * s, x1 * s);
+  float r0, r1;
+  // x s - h in one instruction each: the fp16 half is converted on the fly, the product is not rounded
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x0), "v"(s), "v"(H));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x1), "v"(s), "v"(H));
+  L = x2_cvt_pk(r0, r1);
+}
+// PRE-SPLIT activations ("split_out").  A tensor whose max |value| is bounded a priori (Gabor / sine / Gaussian outputs)
+// can be split by its PRODUCER with a scale fixed on the host, once per element, instead of by every GEMM that reads it
+// (the forward GEMM of the next layer once per 128-column tile -- 4 x at K = 256 -- and the weight-gradient GEMM once per
+// 256-column tile).  Layout: same rows, same leading dimension, same 16 bytes per 4 consecutive columns -- holding
+//     [h(c) h(c+1) h(c+2) h(c+3) | l(c) .. l(c+3)]   (fp16 each)    instead of   [x(c) .. x(c+3)]   (fp32 each)
+// which is the unit every producer writes (one 16-byte store per lane) and every consumer loads.
+WIRE_DEVINL void wire_store_out4(float* p, const f32x4& o, const float split_scale) {
+  if (split_scale != 0.f) {
+    unsigned h0, l0, h1, l1;
+    x2_split2(o[0], o[1], split_scale, h0, l0);
+    x2_split2(o[2], o[3], split_scale, h1, l1);
+    *reinterpret_cast<wire_u32x4*>(p) = wire_u32x4{h0, h1, l0, l1};
+  } else {
+    *reinterpret_cast<f32x4*>(p) = o;
+  }
+}

@@ -44,6 +44,9 @@ struct GemmEpiParams {
   const unsigned* amax_a = nullptr;   //   of the activation operand A (filled by A's producer)
   const unsigned* amax_b = nullptr;   //   of the weight image (filled by launch_amax over the fp32 image)
   unsigned* amax_out = nullptr;       //   of the tensor this epilogue writes for the next GEMM (out / g_lin); may be null
+  // pre-split activations (wire_dev.h: wire_store_out4), 2 x fp16 kernels only:
+  float o1_split = 0.f;               //   != 0: the forward epilogue stores o1 (out) split with this power-of-two scale
+  float a_split_inv = 0.f;            //   != 0: A is such a pre-split tensor; 1 / its scale (amax_a is not read)
 #ifdef WIRE_ABLATE
   int ablate = 0;                // tools/gemm_tune only: 1 no global loads, 2 no LDS writes, 4 no barrier
 #endif
@@ -128,4 +131,4 @@ bool gemmx2_tn_applies(int Pm, int Pn);
 int gemmx2_tn_splits(int64_t n, int Pm, int Pn, int max_splits);
 hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n, int Pm,
                             int Pn, int splits, float* slab, float* bslab, const unsigned* amax_g,
-                            const unsigned* amax_z);
+                            const unsigned* amax_z, float z_pre_inv = 0.f);

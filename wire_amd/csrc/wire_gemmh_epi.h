@@ -95,7 +95,7 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[NRB][8], const GemmEpiParams& ep, const
               o[q] = col + q < ep.kvalid ? v : 0.f;                // pad features are written as 0
             }
             if constexpr (X2) h_amax4(amx, o);
-            if (row < M) *reinterpret_cast<f32x4*>(ep.o1 + (size_t)row * ep.ld1 + col) = o;
+            if (row < M) wire_store_out4(ep.o1 + (size_t)row * ep.ld1 + col, o, X2 ? ep.o1_split : 0.f);
           }
         }
       }
@@ -228,8 +228,8 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[NRB][8], const GemmEpiParams& ep, const
           if constexpr (X2) { h_amax4(amx, o_re); h_amax4(amx, o_im); }
           if (row < M) {
             float* Op = ep.o1 + (size_t)row * ep.ld1 + oc;
-            *reinterpret_cast<f32x4*>(Op) = o_re;
-            *reinterpret_cast<f32x4*>(Op + 32) = o_im;
+            wire_store_out4(Op, o_re, X2 ? ep.o1_split : 0.f);
+            wire_store_out4(Op + 32, o_im, X2 ? ep.o1_split : 0.f);
           }
         }
       }
@@ -454,8 +454,8 @@ WIRE_DEVINL void h_epilogue(f32x4 (&acc)[NRB][8], const GemmEpiParams& ep, const
               if constexpr (X2) { h_amax4(amx, o_re); h_amax4(amx, o_im); }
               if (row < M) {
                 float* Op = ep.o1 + (size_t)row * ep.ld1 + c0;
-                *reinterpret_cast<f32x4*>(Op) = o_re;
-                *reinterpret_cast<f32x4*>(Op + 32) = o_im;
+                wire_store_out4(Op, o_re, X2 ? ep.o1_split : 0.f);
+                wire_store_out4(Op + 32, o_im, X2 ? ep.o1_split : 0.f);
               }
             }
           }

@@ -57,20 +57,6 @@ typedef unsigned x2u32x2 __attribute__((ext_vector_type(2)));
 #define X2_BPLANE (X2_TBN * 64)        // 128 columns x 32 k fp16
 #define X2_BSTAGE (2 * X2_BPLANE)      // planes h, l
 
-WIRE_DEVINL unsigned x2_cvt_pk(float a, float b) {
-  const f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));     // v_cvt_pk_f16_f32 (round to nearest)
-}
-// (x0, x1) s = H + L in packed fp16 pairs (low half = first element): 6 vector ops
-WIRE_DEVINL void x2_split2(float x0, float x1, float s, unsigned& H, unsigned& L) {
-  H = x2_cvt_pk(x0 * s, x1 * s);
-  float r0, r1;
-  // x s - h in one instruction each: the fp16 half is converted on the fly, the product is not rounded
-  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x0), "v"(s), "v"(H));
-  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x1), "v"(s), "v"(H));
-  L = x2_cvt_pk(r0, r1);
-}
-
 #define X2_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 
 WIRE_DEVINL void x2_dma16(const void* gsrc, unsigned char* lds_piece) {
@@ -147,12 +133,16 @@ hipError_t launch_x2_split_b_batch(hipStream_t s, const X2SplitBatch& sb, int nb
 // accumulator registers, <= 168 registers in all: THREE workgroups per CU (AMODE 1 only: LDS holds the weight stages alone).
 // PFD = stages of prefetch distance: 1 -> the rows and weight pieces of stage kt + 1 go out during stage kt; 2 (NRB 2, AMODE 1
 // only: it needs a second set of raw-fragment registers and a third weight buffer) -> those of stage kt + 2.
-template <int EPI, int AMODE, int NRB, int PFD = 1>
+// APRE: A is a pre-split activation (wire_dev.h: wire_store_out4; scale fixed on the host, ep.a_split_inv): the 32 bytes a
+// lane loads per 16-row block ARE its two fragments up to a register shuffle -- no vector arithmetic between the loads and
+// the MFMAs (measured with the loaded bytes taken as the fragments, profiles/r03_gemm_x2_presplit_probe.txt: - 7 % per launch).
+template <int EPI, int AMODE, int NRB, int PFD = 1, bool APRE = false>
 __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(const float* __restrict__ A, int lda,
                                                             const unsigned short* __restrict__ Bx2, int M, int Nc,
                                                             int Kd, int tiles_m, int tiles_n, GemmEpiParams ep) {
   static_assert(NRB == 4 || AMODE == 1, "the 128-row tile loads A straight into registers");
   static_assert(PFD == 1 || (PFD == 2 && NRB == 2 && AMODE == 1), "two stages of prefetch: 128-row tile, A in registers");
+  static_assert(!APRE || (AMODE == 1 && NRB == 4 && PFD == 1), "pre-split A: the default edition only");
   constexpr int A_LDS = NRB == 4 ? X2_ABYTES : 0;      // (AMODE 1 at NRB 4: this part only serves the epilogues' reductions)
   constexpr int TBM = 64 * NRB;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[A_LDS + (PFD + 1) * X2_BSTAGE];
@@ -169,7 +159,8 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
 
   // operand scales from the producers' maxima (uniform; a kernel boundary lies between the producers and this read)
   float s_a, inv_a, s_b, inv_b;
-  wire_x2_scales(wire_amax_read(ep.amax_a, lane), s_a, inv_a);
+  if constexpr (APRE) { s_a = 1.f; inv_a = ep.a_split_inv; }
+  else wire_x2_scales(wire_amax_read(ep.amax_a, lane), s_a, inv_a);
   wire_x2_scales(wire_amax_read(ep.amax_b, lane), s_b, inv_b);
   (void)s_b;
 
@@ -336,15 +327,33 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
       __builtin_amdgcn_sched_barrier(0);
     }
     f16x8 ah[NRB], al[NRB];
+#ifdef WIRE_X2_TILED_PROBE
+    // timing probe (results wrong): the 32 bytes a lane loads per block taken AS the two fp16 fragments -- what the loop
+    // costs when the producer has stored the activation already split (no vector ops between the loads and the MFMAs)
+    if (ep.stagger == 778) {
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+        ah[rb] = __builtin_bit_cast(f16x8, araw[rb][0]);
+        al[rb] = __builtin_bit_cast(f16x8, araw[rb][1]);
+      }
+    } else
+#endif
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) {
-      unsigned H[4], L[4];
-      x2_split2(araw[rb][0][0], araw[rb][0][1], s_a, H[0], L[0]);
-      x2_split2(araw[rb][0][2], araw[rb][0][3], s_a, H[1], L[1]);
-      x2_split2(araw[rb][1][0], araw[rb][1][1], s_a, H[2], L[2]);
-      x2_split2(araw[rb][1][2], araw[rb][1][3], s_a, H[3], L[3]);
-      ah[rb] = __builtin_bit_cast(f16x8, x2u32x4{H[0], H[1], H[2], H[3]});
-      al[rb] = __builtin_bit_cast(f16x8, x2u32x4{L[0], L[1], L[2], L[3]});
+      if constexpr (APRE) {
+        // two 16-byte units [h h h h | l l l l] of 4 columns each -> the 8 h and the 8 l of the lane's k slot
+        const x2u32x4 u0 = __builtin_bit_cast(x2u32x4, araw[rb][0]), u1 = __builtin_bit_cast(x2u32x4, araw[rb][1]);
+        ah[rb] = __builtin_bit_cast(f16x8, x2u32x4{u0[0], u0[1], u1[0], u1[1]});
+        al[rb] = __builtin_bit_cast(f16x8, x2u32x4{u0[2], u0[3], u1[2], u1[3]});
+      } else {
+        unsigned H[4], L[4];
+        x2_split2(araw[rb][0][0], araw[rb][0][1], s_a, H[0], L[0]);
+        x2_split2(araw[rb][0][2], araw[rb][0][3], s_a, H[1], L[1]);
+        x2_split2(araw[rb][1][0], araw[rb][1][1], s_a, H[2], L[2]);
+        x2_split2(araw[rb][1][2], araw[rb][1][3], s_a, H[3], L[3]);
+        ah[rb] = __builtin_bit_cast(f16x8, x2u32x4{H[0], H[1], H[2], H[3]});
+        al[rb] = __builtin_bit_cast(f16x8, x2u32x4{L[0], L[1], L[2], L[3]});
+      }
     }
     if constexpr (AMODE == 1) {
       // the raw registers are free again: next stage's rows and weight pieces go out under this stage's MFMAs
@@ -408,7 +417,8 @@ static hipError_t launchx2h_t(hipStream_t s, const float* A, int lda, const unsi
   // the 128-row editions (three workgroups per CU; optionally two stages of prefetch) are bit-identical and measured no
   // faster (profiles/r03_gemm_x2_rows128.txt, r03_gemm_x2_prefetch2.txt): they are compiled into the harness build only
 #ifdef WIRE_X2_EXPERIMENTS
-  const bool small = g_x2_rows128 != 0 && EPI != EPI_GABOR_BWD_FIRST && EPI != EPI_GABOR2D_BWD_FIRST && !ep.cr_partial;
+  const bool small = g_x2_rows128 != 0 && EPI != EPI_GABOR_BWD_FIRST && EPI != EPI_GABOR2D_BWD_FIRST && !ep.cr_partial &&
+                     ep.a_split_inv == 0.f;
 #else
   const bool small = false;
 #endif
@@ -429,6 +439,17 @@ static hipError_t launchx2h_t(hipStream_t s, const float* A, int lda, const unsi
     }
   }
 #endif
+  if (ep.a_split_inv != 0.f) {
+    // (only the forward forms read an activation; the data gradients read g_lin, which has no a-priori bound)
+    if constexpr (EPI == EPI_STORE || EPI == EPI_GABOR_FWD || EPI == EPI_GABOR2D_FWD || EPI == EPI_SIREN_FWD ||
+                  EPI == EPI_GAUSS_FWD) {
+      hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 1, 4, 1, true>), grid, dim3(256), 0, s, A, lda, Bx2, (int)M, Nc, Kd, tiles_m,
+                         tiles_n, ep);
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if (g_x2_amode == 1)
     hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 1, 4>), grid, dim3(256), 0, s, A, lda, Bx2, (int)M, Nc, Kd, tiles_m, tiles_n, ep);
   else
@@ -440,7 +461,8 @@ static hipError_t launchx2h_t(hipStream_t s, const float* A, int lda, const unsi
 hipError_t launch_gemmx2h_nt(hipStream_t s, int epi, const float* A, int lda, const void* Bx2v, int64_t M, int Nc,
                              int Kd, const GemmEpiParams& ep) {
   if (M <= 0) return hipSuccess;
-  if ((Nc & 63) || (Kd & 31) || (lda & 3) || M > 0x7fffff00LL || !ep.amax_a || !ep.amax_b) return hipErrorInvalidValue;
+  if ((Nc & 63) || (Kd & 31) || (lda & 3) || M > 0x7fffff00LL || (!ep.amax_a && ep.a_split_inv == 0.f) || !ep.amax_b)
+    return hipErrorInvalidValue;
   // 32-bit row offsets inside a 256-row tile
   if ((int64_t)lda * 4 * X2_TBM > 0x7fffffffLL) return hipErrorInvalidValue;
   const unsigned short* Bx2 = (const unsigned short*)Bx2v;
@@ -494,11 +516,11 @@ WIRE_DEVINL x2s16x4 x2_lds_tr16(const unsigned char* p) {
       (x2s16x4 __attribute__((address_space(3)))*)(const_cast<unsigned char*>(p)));
 }
 
-template <int WM, int WN>
+template <int WM, int WN, bool ZPRE>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
     const float* __restrict__ G, int ldg, const float* __restrict__ Z, int ldz, long long n, int Pm, int Pn,
     int tiles_n, int nsplit, long long chunk, float* __restrict__ slab, float* __restrict__ bslab, int tiles,
-    const unsigned* __restrict__ amax_g, const unsigned* __restrict__ amax_z) {
+    const unsigned* __restrict__ amax_g, const unsigned* __restrict__ amax_z, const float z_pre_inv) {
   constexpr int NW = WM * WN;                       // waves
   constexpr int TM = 64 * WM, TN = 128 * WN;        // tile: features of G x features of Z
   constexpr int GPLANE = X2T_TK * TM * 2, ZPLANE = X2T_TK * TN * 2;   // bytes of one fp16 plane of a stage
@@ -524,7 +546,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
 
   float s_g, inv_g, s_z, inv_z;
   wire_x2_scales(wire_amax_read(amax_g, lane), s_g, inv_g);
-  wire_x2_scales(wire_amax_read(amax_z, lane), s_z, inv_z);
+  // ZPRE: Z is a pre-split activation (wire_dev.h: wire_store_out4) -- the 16 bytes a loader lane reads are the 8 + 8 bytes
+  // it stores into the h and l planes; 1 / its scale comes from the host.  (A template parameter: as a run-time branch of
+  // the loader it costs the (WM, 1) shapes 199 spilled registers.)
+  if constexpr (ZPRE) { s_z = 1.f; inv_z = z_pre_inv; }
+  else wire_x2_scales(wire_amax_read(amax_z, lane), s_z, inv_z);
 
   // loader lane = (block of the pair, row slot 0-7, feature quad); unit pair u = (block pair u % P, pass u / P); pass t
   // writes slots 8 t + (0-7), i.e. rows l_row0 + {0, 16, 4, 20}
@@ -610,8 +636,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
         const int fp = ZFIX ? wave : (u & 3), t = ZFIX ? i : (u >> 2);
         const f32x4 zv = R.z[i];
         unsigned h0, l0, h1, l1;
-        x2_split2(zv[0], zv[1], s_z, h0, l0);
-        x2_split2(zv[2], zv[3], s_z, h1, l1);
+        if constexpr (ZPRE) {
+          const x2u32x4 zu = __builtin_bit_cast(x2u32x4, zv);
+          h0 = zu[0]; h1 = zu[1]; l0 = zu[2]; l1 = zu[3];
+        } else {
+          x2_split2(zv[0], zv[1], s_z, h0, l0);
+          x2_split2(zv[2], zv[3], s_z, h1, l1);
+        }
         unsigned char* d = S + 2 * GPLANE + fp * 2048 + t * 256;
         *reinterpret_cast<x2u32x2*>(d) = x2u32x2{h0, h1};
         *reinterpret_cast<x2u32x2*>(d + ZPLANE) = x2u32x2{l0, l1};
@@ -764,24 +795,34 @@ int gemmx2_tn_splits(int64_t n, int Pm, int Pn, int max_splits) {
 template <int WM, int WN>
 static hipError_t launch_x2_tn_t(hipStream_t s, dim3 grid, const float* G, int ldg, const float* Z, int ldz, int64_t n,
                                  int Pm, int Pn, int tiles_n, int used, long long chunk, float* slab, float* bslab,
-                                 int tiles, const unsigned* amax_g, const unsigned* amax_z) {
+                                 int tiles, const unsigned* amax_g, const unsigned* amax_z, float z_pre_inv) {
   constexpr int STAGE = X2T_TK * (64 * WM + 128 * WN) * 4;
   // > 64 KB of dynamic LDS needs the opt-in; per launch (a host-side call of about a microsecond), because the attribute
   // belongs to the current device's copy of the function and a process may drive more than one
-  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemmx2_tn16_kernel<WM, WN>),
+  if (z_pre_inv != 0.f) {
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemmx2_tn16_kernel<WM, WN, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((gemmx2_tn16_kernel<WM, WN, true>), grid, dim3(64 * WM * WN), 2 * STAGE, s, G, ldg, Z, ldz,
+                       (long long)n, Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles, amax_g, amax_z, z_pre_inv);
+    return hipGetLastError();
+  }
+  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemmx2_tn16_kernel<WM, WN, false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
   if (attr != hipSuccess) return attr;
-  hipLaunchKernelGGL((gemmx2_tn16_kernel<WM, WN>), grid, dim3(64 * WM * WN), 2 * STAGE, s, G, ldg, Z, ldz, (long long)n,
-                     Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles, amax_g, amax_z);
+  hipLaunchKernelGGL((gemmx2_tn16_kernel<WM, WN, false>), grid, dim3(64 * WM * WN), 2 * STAGE, s, G, ldg, Z, ldz,
+                     (long long)n, Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles, amax_g, amax_z, z_pre_inv);
   return hipGetLastError();
 }
 
-// `splits` from gemmx2_tn_splits; slabs [splits][Pm][Pn] (+ bslab [splits][Pm]) as launch_gemmx3_tn writes them
+// `splits` from gemmx2_tn_splits; slabs [splits][Pm][Pn] (+ bslab [splits][Pm]) as launch_gemmx3_tn writes them.
+// z_pre_inv != 0: Z is a pre-split activation (wire_dev.h: wire_store_out4), 1 / its scale; amax_z is not read.
 hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n, int Pm,
                             int Pn, int splits, float* slab, float* bslab, const unsigned* amax_g,
-                            const unsigned* amax_z) {
+                            const unsigned* amax_z, float z_pre_inv) {
   const int shp = x2_tn_shape(Pm, Pn);
-  if (!shp || (ldg & 3) || (ldz & 3) || splits < 1 || n < 1 || !amax_g || !amax_z) return hipErrorInvalidValue;
+  if (!shp || (ldg & 3) || (ldz & 3) || splits < 1 || n < 1 || !amax_g || (!amax_z && z_pre_inv == 0.f))
+    return hipErrorInvalidValue;
   const int TMf = 64 * (shp / 10), TNf = 128 * (shp % 10);
   const int tiles_m = Pm / TMf, tiles_n = (Pn + TNf - 1) / TNf;
   long long chunk = (n + splits - 1) / splits;
@@ -797,7 +838,7 @@ hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float*
       if (e != hipSuccess) return e;
     }
   }
-#define X2_TN_ARGS s, grid, G, ldg, Z, ldz, n, Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles_m * tiles_n, amax_g, amax_z
+#define X2_TN_ARGS s, grid, G, ldg, Z, ldz, n, Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles_m * tiles_n, amax_g, amax_z, z_pre_inv
   switch (shp) {
     case 42: return launch_x2_tn_t<4, 2>(X2_TN_ARGS);
     case 61: return launch_x2_tn_t<6, 1>(X2_TN_ARGS);
