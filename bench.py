@@ -461,7 +461,9 @@ def main():
                                    f"(hidden_features={args.hidden_features}), D=2 O=3 omega0=20 sigma0=30, "
                                    f"batch=262144 coords/GPU, fwd+MSE+bwd+Adam per step",
                        "global_batch": npts, "parallelism": f"dp{world}", "micro_shards": args.micro_shards,
-                       "shuffle": args.shuffle, "backend": backend if world > 1 else None},
+                       "shuffle": args.shuffle, "backend": backend if world > 1 else None,
+                       "grad_allreduce": ("per layer, side stream, under the backward" if tr.overlap else
+                                          "whole buffer after the backward") if tr.reducers[0].active else None},
             "roofline": {"bound": "mfma", "kernel": names[klass], "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "mfma_busy": mfma_busy, "pmc_source": pmc_note,

@@ -128,6 +128,22 @@ int wire_train_fwd_bwd(void* stream, const wire_net_desc* d, const float* packed
                        void* act, int64_t act_bytes, void* scratch,
                        int64_t scratch_bytes, void* const* grads_host);
 
+/* The same step for data-parallel callers that overlap the gradient exchange with the rest of the backward
+ * (wire_occupancy.py:137-158 sharded over the GPUs of a node).  `ready(user, first_tensor, n_tensors)` is called ON THE
+ * HOST, from inside this call, each time the kernels that produce the FINAL value of the parameter gradients
+ * grads_host[first_tensor .. first_tensor + n_tensors) (state_dict order) have been enqueued on `stream` -- the final
+ * linear layer first (loss_out is complete by then too), then the hidden layers from the last to the first, the first layer
+ * last; every tensor is announced exactly once.  The callee typically records an event on `stream` and starts the
+ * all-reduce of that slice on another stream; it must not wait for the device.  ready == NULL: wire_train_fwd_bwd.     */
+typedef void (*wire_grad_ready_fn)(void* user, int first_tensor, int n_tensors);
+int wire_train_fwd_bwd_hooked(void* stream, const wire_net_desc* d, const float* packed,
+                              const float* coords, int64_t n, const float* target,
+                              const int64_t* idx, int64_t first, float weight, float* y,
+                              float* g_y, float* loss_out, float* rec, float* partial,
+                              void* act, int64_t act_bytes, void* scratch,
+                              int64_t scratch_bytes, void* const* grads_host,
+                              wire_grad_ready_fn ready, void* user);
+
 /* ---- per-layer path (ComplexGaborLayer.forward, modules/wire.py:88-93) -- */
 /* x: [n][in] f32 when is_first else [n][in] c64; W: [out][in] f32/c64;
  * act_out [n][out] c64 (interleaved); lin_out (optional, may be NULL) receives the pre-activation

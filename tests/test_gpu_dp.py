@@ -44,16 +44,19 @@ def _run(tr, dev, hashed=False):
     return [float(l.item()) for l in losses]
 
 
-def _worker(rank, world, port, micro, out_dir, hashed=False):
+def _worker(rank, world, port, micro, out_dir, hashed=False, overlap="layer"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["WIRE_DP_OVERLAP"] = overlap
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     # hashed mode: the ranks are BUILT from different seeds -- FusedTrainer broadcasts rank 0's parameters
     model, tr = _make(dev, micro, seed=100 + rank if hashed else 0)
     assert tr.world == world and tr.rank == rank
+    # one micro-shard: every layer's gradient slice is reduced as soon as wire_train_fwd_bwd_hooked announces it
+    assert tr.overlap == (micro == 1 and overlap == "layer")
     losses = _run(tr, dev, hashed)
     flat = tr.flat.detach().cpu().numpy()
     np.save(os.path.join(out_dir, f"flat_{rank}.npy"), flat)
@@ -62,10 +65,10 @@ def _worker(rank, world, port, micro, out_dir, hashed=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("micro", [1, 2])
-def test_two_ranks_match_single_process(tmp_path, micro):
-    port = 29700 + (os.getpid() % 1000) + micro
-    mp.spawn(_worker, args=(2, port, micro, str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("micro,overlap", [(1, "layer"), (1, "none"), (2, "layer")])
+def test_two_ranks_match_single_process(tmp_path, micro, overlap):
+    port = 29700 + (os.getpid() % 1000) + micro + (5 if overlap == "none" else 0)
+    mp.spawn(_worker, args=(2, port, micro, str(tmp_path), False, overlap), nprocs=2, join=True)
     dev = torch.device("cuda", 0)
     model, tr = _make(dev, 1)
     ref_losses = _run(tr, dev)
@@ -92,7 +95,7 @@ def test_two_ranks_hashed_shuffle_and_broadcast(tmp_path):
     assert np.abs(f0 - tr.flat.detach().cpu().numpy()).max() < 0.05 * 5e-3
 
 
-def _worker_rccl_direct(rank, world, port, out_dir):
+def _worker_rccl_direct(rank, world, port, out_dir, overlap="layer"):
     """One rank, backend nccl (= RCCL), WIRE_DP_FORCE=1: the collective path stays live, FlatGradAllReducer opens its own
     communicator (parallel.RcclDirect: ncclGetUniqueId -> broadcast of the 128 bytes -> ncclCommInitRank) and issues
     ncclAllReduce on the compute stream."""
@@ -100,12 +103,16 @@ def _worker_rccl_direct(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["WIRE_DP_FORCE"] = "1"
+    os.environ["WIRE_DP_OVERLAP"] = overlap
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     model, tr = _make(dev, 1)
     assert tr.reducers[0].active and tr.reducers[0].direct is not None, "direct RCCL communicator was not set up"
+    # "layer": six ncclAllReduce calls per step on the side stream (final layer + loss, hidden layers, first layer), each
+    # behind an event of the compute stream; "none": one call on the compute stream after the backward
+    assert tr.overlap == (overlap == "layer") and (tr.reducers[0].stream is not None) == (overlap == "layer")
     losses = _run(tr, dev)
     np.save(os.path.join(out_dir, "flat_direct.npy"), tr.flat.detach().cpu().numpy())
     np.save(os.path.join(out_dir, "loss_direct.npy"), np.array(losses))
@@ -118,13 +125,14 @@ def _worker_rccl_direct(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_direct_rccl_allreduce_single_rank_matches_plain_run(tmp_path):
+@pytest.mark.parametrize("overlap", ["layer", "none"])
+def test_direct_rccl_allreduce_single_rank_matches_plain_run(tmp_path, overlap):
     """ncclAllReduce through librccl.so's C ABI on the compute stream (no ProcessGroup stream
     hand-offs).  RCCL refuses two ranks on one device, so a one-GPU box can only run the 1-rank communicator: the whole
     plumbing (unique id, communicator, stream, in-place reduce) with a sum over one rank = the plain trajectory, bit for
     bit.  wire_occupancy.py:137-158 is the loop being sharded."""
-    port = 29500 + (os.getpid() % 400) + 17
-    mp.spawn(_worker_rccl_direct, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    port = 29500 + (os.getpid() % 400) + (17 if overlap == "layer" else 23)
+    mp.spawn(_worker_rccl_direct, args=(1, port, str(tmp_path), overlap), nprocs=1, join=True)
     dev = torch.device("cuda", 0)
     model, tr = _make(dev, 1)
     losses = _run(tr, dev)

@@ -42,19 +42,31 @@ def _worker(rank, world, port, B, bucket, out_dir):
     loss, gy = wo.mse_loss_and_grad(y, target[lo:hi])
     g = wo.wire_backward(P, cache, gy * w, m["L"], m["om1"], m["om"], m["sc"])
     flat = torch.tensor(np.concatenate([_flat(g, order), [loss * w]]))
-    red = FlatGradAllReducer(flat, bucket_floats=bucket)
-    assert red.active and len(red.buckets) == (1 if not bucket else -(-flat.numel() // bucket))
-    red()
+    red = FlatGradAllReducer(flat, bucket_floats=None if bucket == "ranges" else bucket)
+    if bucket == "ranges":
+        # the per-layer overlap of FusedTrainer: slices announced from the last tensor to the first (launch_range), one join
+        assert red.active
+        sizes = [wo.as_real_pairs(g[k]).size for k in order]
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+        nt = len(order)
+        red.launch_range(int(offs[nt - 2]), flat.numel())            # final layer + the loss behind it
+        for t in range(nt - 4, 0, -2):
+            red.launch_range(int(offs[t]), int(offs[t + 2]))
+        red.launch_range(0, int(offs[2]))
+        red.wait()
+    else:
+        assert red.active and len(red.buckets) == (1 if not bucket else -(-flat.numel() // bucket))
+        red()
     if rank == 0:
         np.save(os.path.join(out_dir, "reduced.npy"), flat.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B,bucket", [(256, None), (257, 1000)])
+@pytest.mark.parametrize("B,bucket", [(256, None), (257, 1000), (255, "ranges")])
 def test_sharded_gradient_equals_full_batch(tmp_path, B, bucket):
     from oracle import wire_oracle as wo
-    port = 29500 + (os.getpid() % 2000) + (1 if bucket else 0)
+    port = 29500 + (os.getpid() % 2000) + (0 if not bucket else (1 if bucket == 1000 else 2))
     mp.spawn(_worker, args=(2, port, B, bucket, str(tmp_path)), nprocs=2, join=True)
     red = np.load(tmp_path / "reduced.npy")
     rec = load_golden("small_wire_d2")

@@ -28,7 +28,7 @@ SYMBOLS = [
     "wire_layer_ws_bytes", "wire_gabor_fwd", "wire_gabor_bwd", "wire_final_fwd",
     "wire_final_bwd", "wire_coords_from_index", "wire_mse_grad",
     "wire_adam_step_flat", "wire_blocked_width", "wire_c64_to_blocked",
-    "wire_blocked_to_c64", "wire_prof_enable", "wire_prof_read", "wire_tune_set", "wire_tune_get", "wire_avgpool_mse_grad", "wire_layer2d_ws_bytes", "wire_gabor2d_fwd", "wire_gabor2d_bwd", "wire_eval_metric", "wire_real_layer_fwd", "wire_real_layer_bwd", "wire_train_fwd_bwd", "wire_perm_indices", "wire_gabor_hparam_grad", "wire_track_best", "wire_sigmoid_inplace", "wire_radon_fwd", "wire_radon_bwd", "wire_gabor2d_hparam_grad", "wire_posenc_fwd", "wire_act_out_offset",
+    "wire_blocked_to_c64", "wire_prof_enable", "wire_prof_read", "wire_tune_set", "wire_tune_get", "wire_avgpool_mse_grad", "wire_layer2d_ws_bytes", "wire_gabor2d_fwd", "wire_gabor2d_bwd", "wire_eval_metric", "wire_real_layer_fwd", "wire_real_layer_bwd", "wire_train_fwd_bwd", "wire_perm_indices", "wire_gabor_hparam_grad", "wire_track_best", "wire_sigmoid_inplace", "wire_radon_fwd", "wire_radon_bwd", "wire_gabor2d_hparam_grad", "wire_posenc_fwd", "wire_act_out_offset", "wire_train_fwd_bwd_hooked",
 ]
 
 
@@ -38,6 +38,10 @@ class NetDesc(C.Structure):
                 ("hidden_layers", C.c_int32), ("out_features", C.c_int32),
                 ("posenc_freqs", C.c_int32), ("first_omega0", C.c_float),
                 ("hidden_omega0", C.c_float), ("scale0", C.c_float)]
+
+
+# wire_grad_ready_fn (include/wire_hip.h): void (*)(void* user, int first_tensor, int n_tensors)
+GRAD_READY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int)
 
 
 class WireHipError(RuntimeError):
@@ -96,6 +100,8 @@ def _declare(l: C.CDLL) -> None:
     l.wire_avgpool_mse_grad.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     l.wire_train_fwd_bwd.argtypes = [vp, dp, vp, vp, i64, vp, vp, i64, f32, vp, vp, vp, vp, vp, vp, i64, vp, i64,
                                      C.POINTER(vp)]
+    l.wire_train_fwd_bwd_hooked.argtypes = [vp, dp, vp, vp, i64, vp, vp, i64, f32, vp, vp, vp, vp, vp, vp, i64, vp, i64,
+                                            C.POINTER(vp), GRAD_READY_FN, vp]
     l.wire_real_layer_fwd.argtypes = [vp, i32, vp, vp, vp, f32, f32, i64, i32, i32, vp, vp, i64]
     l.wire_real_layer_bwd.argtypes = [vp, i32, vp, vp, vp, vp, f32, f32, i64, i32, i32, vp, vp, vp, vp, i64]
     l.wire_eval_metric.argtypes = [vp, i32, vp, vp, i64, f32, vp, vp]

@@ -570,7 +570,8 @@ extern "C" int wire_mlp_fwd(void* stream, const wire_net_desc* d, const float* p
 // g_lin of layer L is in the scratch's first gradient buffer and the final-layer partials are there.
 static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const float* coords, int64_t n,
                         const float* g_y, const void* act, int64_t act_bytes, void* scratch,
-                        int64_t scratch_bytes, void* const* grads, bool do_final) {
+                        int64_t scratch_bytes, void* const* grads, bool do_final,
+                        wire_grad_ready_fn ready = nullptr, void* user = nullptr) {
   if (n <= 0) return fail(WIRE_ERR_ARG, "backward needs n > 0");
   if (!packed || !coords || (do_final && !g_y) || !act || !scratch || !grads) return fail(WIRE_ERR_ARG, "null pointer");
   for (int i = 0; i < p.ntens; ++i) if (!grads[i]) return fail(WIRE_ERR_ARG, "grads[%d] is null", i);
@@ -605,6 +606,7 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
     ProfScope ps(s, 3, 0);
     HIPCHK(launch_final_reduce(s, p.kind, Sx + sc.fpw, Sx + sc.fpb, nbf, p.O, p.K, p.P,
                                (float*)grads[p.ntens - 2], (float*)grads[p.ntens - 1]));
+    if (ready) ready(user, p.ntens - 2, 2);
   } else {
     ProfScope ps(s, 3, 0);
     const float wL = (p.L == 0) ? p.w1 : p.w;
@@ -619,6 +621,7 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
     }
     HIPCHK(launch_final_reduce(s, p.kind, Sx + sc.fpw, Sx + sc.fpb, nbf, p.O, p.K, p.P,
                                (float*)grads[p.ntens - 2], (float*)grads[p.ntens - 1]));
+    if (ready) ready(user, p.ntens - 2, 2);
   }
   if (p.L == 0 && p.cplx) {
     // no hidden layer (net = first Gabor layer + final linear): gcur holds the raw g_out0; the first layer's
@@ -648,6 +651,7 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
                                 Sx + sc.bslab)); }
       ProfScope ps(s, 3, 0);
       HIPCHK(launch_wgrad3m_reduce(s, Sx + sc.slab, Sx + sc.bslab, S, p.K, p.K, p.Kp, p.Kp, gW, gb));
+      if (ready) ready(user, p.per_layer * l, p.per_layer);
     } else {
       const bool x2tn = x2 && gemmx2_tn_applies(p.Pl, p.P);
       const int S = x2tn ? gemmx2_tn_splits(n, p.Pl, p.P, sc.S)
@@ -668,6 +672,7 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
       ProfScope ps(s, 3, 0);
       HIPCHK(launch_wgrad_reduce(s, p.kind, Sx + sc.slab, Sx + sc.bslab, S, p.K, p.K, p.Pl, p.P, gW,
                                  gb, gV, gc));
+      if (ready) ready(user, p.per_layer * l, p.per_layer);
     }
     GemmEpiParams ep;
     ep.scale = p.s; ep.kvalid = p.K; ep.ld1 = p.P; ep.i1 = out_l(l - 1);
@@ -744,6 +749,7 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
     HIPCHK(launch_wgrad_reduce(s, p.kind, Sx + sc.slab, Sx + sc.bslab, S, p.K, p.Din, p.P, p.Pin0,
                                (float*)grads[0], (float*)grads[1], nullptr, nullptr));
   }
+  if (ready) ready(user, 0, p.per_layer);
   return WIRE_OK;
 }
 
@@ -758,11 +764,12 @@ extern "C" int wire_mlp_bwd(void* stream, const wire_net_desc* d, const float* p
 // ---------------------------------------------------------------------------
 // fused training core: forward -> MSE -> backward in one call
 // ---------------------------------------------------------------------------
-extern "C" int wire_train_fwd_bwd(void* stream, const wire_net_desc* d, const float* packed,
-                                  const float* coords, int64_t n, const float* target, const int64_t* idx,
-                                  int64_t first, float weight, float* y, float* g_y, float* loss_out,
-                                  float* rec, float* partial, void* act, int64_t act_bytes, void* scratch,
-                                  int64_t scratch_bytes, void* const* grads) {
+extern "C" int wire_train_fwd_bwd_hooked(void* stream, const wire_net_desc* d, const float* packed,
+                                         const float* coords, int64_t n, const float* target, const int64_t* idx,
+                                         int64_t first, float weight, float* y, float* g_y, float* loss_out,
+                                         float* rec, float* partial, void* act, int64_t act_bytes, void* scratch,
+                                         int64_t scratch_bytes, void* const* grads, wire_grad_ready_fn ready,
+                                         void* user) {
   Plan p; if (int rc = make_plan(d, p)) return rc;
   if (n <= 0) return fail(WIRE_ERR_ARG, "wire_train_fwd_bwd needs n > 0");
   if (!target || !y || !g_y || !loss_out || !partial) return fail(WIRE_ERR_ARG, "null pointer");
@@ -774,7 +781,8 @@ extern "C" int wire_train_fwd_bwd(void* stream, const wire_net_desc* d, const fl
     if (int rc = mlp_fwd_core(stream, p, packed, coords, n, y, act, act_bytes, 1, true)) return rc;
     { ProfScope ps(s, 3, 0);
       HIPCHK(launch_mse_grad(s, y, target, idx, first, n, p.O, weight, g_y, loss_out, rec, partial)); }
-    return mlp_bwd_core(stream, p, packed, coords, n, g_y, act, act_bytes, scratch, scratch_bytes, grads, true);
+    return mlp_bwd_core(stream, p, packed, coords, n, g_y, act, act_bytes, scratch, scratch_bytes, grads, true, ready,
+                        user);
   }
   // with layer L on the 16 x 16 x 32 forward kernel (lean epilogue) the final stage evaluates out_L from lin_L itself,
   // bit for bit what that epilogue would have stored: out_L is neither written nor read (1 GB less HBM traffic)
@@ -798,7 +806,16 @@ extern "C" int wire_train_fwd_bwd(void* stream, const wire_net_desc* d, const fl
                               p.w, p.s, y, rec, Sx + sc.ga, Sx + sc.fpw, Sx + sc.fpb, Sx + sc.crp, loss_out,
                               x2 ? gamax + p.L * WIRE_AMAX_SLOTS : nullptr));
   }
-  return mlp_bwd_core(stream, p, packed, coords, n, nullptr, act, act_bytes, scratch, scratch_bytes, grads, false);
+  return mlp_bwd_core(stream, p, packed, coords, n, nullptr, act, act_bytes, scratch, scratch_bytes, grads, false, ready,
+                      user);
+}
+extern "C" int wire_train_fwd_bwd(void* stream, const wire_net_desc* d, const float* packed,
+                                  const float* coords, int64_t n, const float* target, const int64_t* idx,
+                                  int64_t first, float weight, float* y, float* g_y, float* loss_out,
+                                  float* rec, float* partial, void* act, int64_t act_bytes, void* scratch,
+                                  int64_t scratch_bytes, void* const* grads) {
+  return wire_train_fwd_bwd_hooked(stream, d, packed, coords, n, target, idx, first, weight, y, g_y, loss_out, rec, partial,
+                                   act, act_bytes, scratch, scratch_bytes, grads, nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------------------

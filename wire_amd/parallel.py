@@ -150,7 +150,7 @@ class FlatGradAllReducer:
         # through the process group's own stream; WIRE_DP_DIRECT=0 keeps torch.distributed.all_reduce.  Any failure to
         # set the communicator up falls back to the process group (every rank takes the same branch: the outcome is
         # agreed on with a MIN all-reduce).
-        if (self.active and flat.is_cuda and self.stream is None and not self.stage_host
+        if (self.active and flat.is_cuda and not self.stage_host
                 and dist.get_backend(group) == "nccl" and os.environ.get("WIRE_DP_DIRECT", "1") != "0"):
             key = (flat.device.index, id(group))
             comm = FlatGradAllReducer._direct_comms.get(key)
@@ -177,8 +177,14 @@ class FlatGradAllReducer:
             return
         t = self.flat if tensor is None else tensor
         if self.direct is not None:
-            for lo, hi in self.buckets:
-                self.direct.all_reduce_sum_(t[lo:hi])
+            if self.stream is not None:
+                self.stream.wait_stream(torch.cuda.current_stream(t.device))
+                with torch.cuda.stream(self.stream):
+                    for lo, hi in self.buckets:
+                        self.direct.all_reduce_sum_(t[lo:hi])
+            else:
+                for lo, hi in self.buckets:
+                    self.direct.all_reduce_sum_(t[lo:hi])
             return
         if self.stage_host:
             host = t.detach().cpu()
@@ -195,6 +201,32 @@ class FlatGradAllReducer:
             for lo, hi in self.buckets:
                 self._pending.append(dist.all_reduce(t[lo:hi], op=dist.ReduceOp.SUM,
                                                      group=self.group, async_op=True))
+
+    def launch_range(self, lo: int, hi: int) -> None:
+        """Start the all-reduce of flat[lo:hi] behind everything the compute stream holds so far and return at once:
+        the per-layer overlap of FusedTrainer (a layer's gradient slice is reduced on the side stream while the compute
+        stream goes on with the backward of the layers below it).  ``wait()`` joins the streams again.  Every rank
+        calls this with the same ranges in the same order."""
+        if not self.active or hi <= lo:
+            return
+        t = self.flat[lo:hi]
+        if self.stage_host:
+            host = t.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(host)
+            return
+        if self.stream is None or not t.is_cuda:
+            if self.direct is not None:
+                self.direct.all_reduce_sum_(t)
+            else:
+                self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        self.stream.wait_stream(torch.cuda.current_stream(t.device))
+        with torch.cuda.stream(self.stream):
+            if self.direct is not None:
+                self.direct.all_reduce_sum_(t)
+            else:
+                self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self) -> None:
         """Make the compute stream (or the host, on CPU) wait for the collective."""

@@ -14,10 +14,11 @@ pairs, exactly torch.optim.Adam's arithmetic) are HIP kernels.  The host gather
 + H2D copy and the per-step ``loss.item()`` of the reference are gone.
 
 Multi-GPU: one process per GPU; the global batch is sharded contiguously
-(parallel.shard_bounds), each shard's gradient is pre-scaled by n_g/B and one
-RCCL all-reduce (SUM) of the flat gradient buffer runs on a side stream.  With
-``micro_shards > 1`` the all-reduce of micro-shard i overlaps the forward and
-backward of micro-shard i+1.
+(parallel.shard_bounds), each shard's gradient is pre-scaled by n_g/B and the flat
+gradient buffer is all-reduced (SUM) over RCCL: in one piece on the compute stream
+after the backward (default), layer by layer on a side stream as soon as the backward
+has produced each slice (WIRE_DP_OVERLAP=layer, wire_train_fwd_bwd_hooked), or -- with
+``micro_shards > 1`` -- micro-shard i's under the forward and backward of micro-shard i+1.
 """
 from __future__ import annotations
 
@@ -115,7 +116,17 @@ class FusedTrainer:
         # (two cross-stream hand-offs fewer per step); several: a side stream overlaps it with the next shard
         side = self.micro > 1 and os.environ.get("WIRE_DP_SIDE_STREAM", "1") != "0" or \
             os.environ.get("WIRE_DP_SIDE_STREAM", "") == "1"
-        self.reducers = [FlatGradAllReducer(g, group, use_side_stream=side) for g in self.gbuf]
+        # WIRE_DP_OVERLAP=layer (one micro-shard): PER-LAYER overlap -- wire_train_fwd_bwd_hooked announces each layer's
+        # gradient as soon as its last kernel is enqueued, and that slice of the flat buffer is all-reduced on a side stream
+        # while the compute stream runs the backward of the layers below it; only the first layer's (smallest, last) slice is
+        # exposed.  Default "none": one all-reduce of the whole 2.1 MB buffer after the backward -- measured on the one-rank
+        # communicator (tools/dp_overhead.sh) the six cross-stream hand-offs of "layer" cost 0.07 - 0.09 ms per step, as
+        # much as the whole latency-bound all-reduce they would hide.
+        self.overlap = self.micro == 1 and os.environ.get("WIRE_DP_OVERLAP", "none") == "layer"
+        self.reducers = [FlatGradAllReducer(g, group, use_side_stream=side or self.overlap) for g in self.gbuf]
+        self.overlap = self.overlap and self.reducers[0].active
+        self._cb_err: Optional[BaseException] = None
+        self._ready_cb = _lib.GRAD_READY_FN(self._on_grad_ready)     # (kept alive with the trainer)
         self._cap = 0
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self._hidx: Optional[torch.Tensor] = None
@@ -133,6 +144,26 @@ class FusedTrainer:
         else:
             dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
                            group=self.group)
+
+    def _ready_order(self):
+        """(first_tensor, n_tensors) in the order wire_train_fwd_bwd_hooked announces them (include/wire_hip.h)."""
+        nt = len(self.offsets)
+        hidden = int(self.desc.hidden_layers)
+        per = (nt - 2) // (hidden + 1)
+        yield nt - 2, 2
+        for l in range(hidden, 0, -1):
+            yield per * l, per
+        yield 0, per
+
+    def _on_grad_ready(self, user, first: int, n: int) -> None:
+        """wire_grad_ready_fn: parameter tensors [first, first + n) have their final gradient enqueued on the compute
+        stream -> start the all-reduce of their slice of the flat buffer (the loss rides behind the last tensor)."""
+        try:
+            lo = self.offsets[first]
+            hi = self.offsets[first + n] if first + n < len(self.offsets) else self.count + 1
+            self.reducers[0].launch_range(lo, hi)
+        except BaseException as e:                       # noqa: BLE001 -- must not propagate through the C frame
+            self._cb_err = e
 
     # ------------------------------------------------------------------ buffers
     def _reserve(self, n: int) -> None:
@@ -239,18 +270,30 @@ class FusedTrainer:
             g = self.gbuf[m]
             if n == 0:
                 g.zero_()
+                if self.overlap:                         # the same slices in the same order as the ranks that have rows
+                    for t0, nt in self._ready_order():
+                        self._on_grad_ready(None, t0, nt)
+                    if self._cb_err is not None:
+                        raise self._cb_err
+                    continue
             else:
                 ip = (idx_ptr + 8 * mlo) if idx_ptr is not None else None
                 _lib.check(L.wire_coords_from_index(stream, ip, first + mlo, n, self.tx.data_ptr(),
                                                     self.grid[1], self.ty.data_ptr(), self.grid[0],
                                                     tz_ptr, Tn, self.coords.data_ptr()), "coords")
-                _lib.check(L.wire_train_fwd_bwd(
-                    stream, d, self.packed.data_ptr(), self.coords.data_ptr(), n, self.target.data_ptr(),
-                    ip, first + mlo, n / float(B), self.y.data_ptr(), self.gy.data_ptr(),
-                    g.data_ptr() + 4 * self.count,
-                    self.rec.data_ptr() if self.rec is not None else None, self.partial.data_ptr(),
-                    self.act.data_ptr(), self.act_bytes, self.scratch.data_ptr(), self.scr_bytes,
-                    self.grad_ptrs[m]), "train_fwd_bwd")
+                args = (stream, d, self.packed.data_ptr(), self.coords.data_ptr(), n, self.target.data_ptr(),
+                        ip, first + mlo, n / float(B), self.y.data_ptr(), self.gy.data_ptr(),
+                        g.data_ptr() + 4 * self.count,
+                        self.rec.data_ptr() if self.rec is not None else None, self.partial.data_ptr(),
+                        self.act.data_ptr(), self.act_bytes, self.scratch.data_ptr(), self.scr_bytes,
+                        self.grad_ptrs[m])
+                if self.overlap:
+                    self._cb_err = None
+                    _lib.check(L.wire_train_fwd_bwd_hooked(*args, self._ready_cb, None), "train_fwd_bwd")
+                    if self._cb_err is not None:
+                        raise self._cb_err
+                    continue                             # every slice is on its way: wait() below joins the streams
+                _lib.check(L.wire_train_fwd_bwd(*args), "train_fwd_bwd")
             self.reducers[m].launch()
         for r in self.reducers:
             r.wait()
