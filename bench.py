@@ -222,6 +222,69 @@ def timed_config(dev, lib, kind, side, hf, steps, warmup=2, **kw):
     return res
 
 
+def reference_loop(dev, wire_kw, epochs=6, device_resident=False):
+    import torch
+    from torch.optim.lr_scheduler import LambdaLR
+    from wire_amd.modules import models
+    H = W = SIDE
+    maxpoints = H * W
+    torch.manual_seed(0)
+    model = models.get_INR(nonlin="wire", in_features=D, out_features=O, hidden_features=HIDDEN_FEATURES,
+                           hidden_layers=L, **wire_kw)
+    model.cuda()
+    x = torch.linspace(-1, 1, W)
+    y = torch.linspace(-1, 1, H)
+    X, Y = torch.meshgrid(x, y, indexing="xy")
+    coords = torch.hstack((X.reshape(-1, 1), Y.reshape(-1, 1)))[None, ...]
+    if device_resident:
+        coords = coords.cuda()
+    g = torch.Generator().manual_seed(0)
+    gt = torch.rand(H * W, O, generator=g).cuda()[None, ...]
+    gt_noisy = gt + 0.01
+    optim = torch.optim.Adam(lr=5e-3 * min(1, maxpoints / (H * W)), params=model.parameters())
+    scheduler = LambdaLR(optim, lambda e: 0.1 ** min(e / 2000, 1))
+    mse_loss_array = torch.zeros(epochs + 2, device="cuda")
+    mse_array = torch.zeros(epochs + 2, device="cuda")
+    rec = torch.zeros_like(gt)
+    t_dev = 0.0
+    for epoch in range(epochs + 2):
+        if epoch == 2:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        indices = torch.randperm(H * W, device="cuda") if device_resident else torch.randperm(H * W)
+        for b_idx in range(0, H * W, maxpoints):
+            b_indices = indices[b_idx:min(H * W, b_idx + maxpoints)]
+            b_coords = coords[:, b_indices, ...].cuda()
+            b_indices = b_indices.cuda()
+            pixelvalues = model(b_coords)
+            with torch.no_grad():
+                rec[:, b_indices, :] = pixelvalues
+            loss = ((pixelvalues - gt_noisy[:, b_indices, :]) ** 2).mean()
+            optim.zero_grad()
+            loss.backward()
+            optim.step()
+        with torch.no_grad():
+            if device_resident:                           # the same bookkeeping without host round trips
+                mse_loss_array[epoch] = ((gt_noisy - rec) ** 2).mean()
+                mse_array[epoch] = ((gt - rec) ** 2).mean()
+            else:
+                mse_loss_array[epoch] = ((gt_noisy - rec) ** 2).mean().item()
+                mse_array[epoch] = ((gt - rec) ** 2).mean().item()
+        scheduler.step()
+        if not device_resident:
+            imrec = rec[0, ...].reshape(H, W, O).detach().cpu().numpy()   # noqa: F841 -- the reference's per-epoch copy
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / epochs
+    del model, optim
+    torch.cuda.empty_cache()
+    note = ("the same calls with coords / randperm on the device and no .item() / D2H per epoch: what the module path "
+            "(model(b_coords) + autograd + torch.optim.Adam) itself sustains") if device_resident else \
+        ("wire_image_denoise.py:141-178 verbatim (maxpoints = H W) on the headline net through wire_amd.modules + "
+         "autograd + torch.optim.Adam, host work of the reference's loop included (CPU randperm and gather, H2D, "
+         "two .item(), D2H of rec per epoch)")
+    return {"samples_per_s": H * W / dt, "ms_per_epoch": dt * 1e3, "epochs": epochs, "note": note}
+
+
 def extras(dev, lib):
     """Secondary numbers (not the headline)."""
     import torch
@@ -289,6 +352,11 @@ def extras(dev, lib):
                                        "instead of wire_perm_indices"}
     del tr, model
     torch.cuda.empty_cache()
+    # the reference's loop UNCHANGED (wire_image_denoise.py:141-178 with maxpoints = H W: one minibatch per epoch) through the
+    # drop-in modules -- model(b_coords), autograd backward (wire_mlp_fwd / wire_mlp_bwd), torch.optim.Adam, and the
+    # reference's own host work per epoch: CPU randperm, CPU gather of the coordinates + H2D, two .item() syncs, D2H of rec
+    res["reference_loop_unchanged"] = reference_loop(dev, wire_kw)
+    res["reference_loop_device_resident"] = reference_loop(dev, wire_kw, device_resident=True)
     # BASELINE.json configs[3] and [4] through the same trainer (bounded steps)
     res["cfg4_wire2d_4x256_1024x1024"] = timed_config(dev, lib, "wire2d", 1024, 256, 4, first_omega_0=10.0,
                                                       hidden_omega_0=10.0, scale=10.0)
