@@ -300,8 +300,10 @@ int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* 
  *     three partial products per fp32 product (h h + h l + l h), fp32 accumulate -- fp32-accurate (measured rms error
  *     0.64 - 0.78 x the fp32 MFMA chain's, tools/f16x2_numerics.hip) at half the matrix-core work of the 3 x bf16
  *     split.  The maxima are tracked on the device by each tensor's producer kernel (64 sharded atomicMax slots inside
- *     the act / scratch / packed buffers) and read by the consumer kernel: no host round trip.  "x2_amode" (default 1):
- *     1 = the activation operand goes from global memory straight into fragment registers, 0 = through LDS.
+ *     the act / scratch / packed buffers) and read by the consumer kernel: no host round trip.  "x2_amode" (default 2):
+ *     how the forward / data-gradient GEMM reads its activation operand -- 2 = through LDS in whole 128-byte lines (8 rows
+ *     per LDS-DMA instruction, bank swizzle on the source address), 1 = straight into fragment registers (16 rows x 64
+ *     bytes per instruction), 0 = through LDS in such half-line pieces; bit-identical results.
  *     0 = the 3 x bf16 kernels below for every batch size.
  * "split_out" (default 1; environment WIRE_SPLIT_OUT; with split_f16): the activations out_l of the INNER hidden layers
  *     (1 <= l < hidden_layers) of a wire / wire2d / siren / gauss net are stored ALREADY SPLIT by the forward epilogue --
@@ -337,7 +339,7 @@ int wire_blocked_to_c64(void* stream, const float* src, int64_t n, int K, void* 
  * backward re-derives from them which kernel edition produced the activations (recompute_out: the lean forward form
  * whose bits it reproduces) and whether the forward filled the max-|value| slots the 2 x fp16 kernels scale by.     */
 int wire_tune_set(const char* key, int value);
-int wire_tune_get(const char* key);   /* "split_bf16" | "split_f16" | "split_out" | "complex_3m" | "x3_h16" | "x3_tn16" | "recompute_out" -> value; < 0 = error */
+int wire_tune_get(const char* key);   /* "split_bf16" | "split_f16" | "split_out" | "x2_amode" | "complex_3m" | "x3_h16" | "x3_tn16" | "recompute_out" -> value; < 0 = error */
 
 /* ---- profiling hooks (bench.py roofline) -------------------------------
  * When enabled, every launch of the hot kernels is bracketed by hipEvents on

@@ -4,6 +4,7 @@
 //   bash tools/build_x2_tune.sh && ./build/gemm_x2_tune [N] [P] [rounds]
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -25,6 +26,12 @@ __global__ void fill_kernel(float* p, size_t n, unsigned seed, float scale, int 
     v *= __expf(-12.f * (y >> 8) * (1.0f / 16777216.0f));
   }
   p[i] = v;
+}
+// plain streaming read of n4 float4 (the HBM traffic of an operand, issued by waves that do nothing else)
+__global__ __launch_bounds__(256) void stream_read_kernel(const float4* __restrict__ src, float* __restrict__ sink, size_t n4) {
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) { const float4 v = src[i]; s += v.x + v.y + v.z + v.w; }
+  if (s == 123.456f) sink[0] = s;
 }
 static float* dalloc(size_t n, unsigned seed, float scale, int gaborlike = 0) {
   float* p; CK(hipMalloc(&p, n * sizeof(float)));
@@ -102,6 +109,14 @@ int main(int argc, char** argv) {
     size_t bad = 0;
     for (size_t i = 0; i < ref.size(); ++i) bad += memcmp(&ref[i], &got[i], 4) != 0;
     printf("   A via registers vs A via LDS: %zu of %zu words differ\n", bad, ref.size());
+    gemmx2h_tune_set("x2_amode", 2);
+    CK(hipMemset(r0, 0xff, (size_t)Nc * P * 4));
+    ep.o0 = r0; CK(launch_gemmx2h_nt(0, EPI_STORE, A, P, Bx2, Nc, P, P, ep));
+    gemmx2h_tune_set("x2_amode", 0);
+    CK(hipMemcpy(ref.data(), r0, ref.size() * 4, hipMemcpyDeviceToHost));
+    bad = 0;
+    for (size_t i = 0; i < ref.size(); ++i) bad += memcmp(&ref[i], &got[i], 4) != 0;
+    printf("   A via LDS in whole lines vs A via LDS: %zu of %zu words differ\n", bad, ref.size());
     // 128-row tiles (3 workgroups per CU): the same arithmetic per element -> the same bits
     gemmx2h_tune_set("x2_rows128", 1);
     CK(hipMemset(r0, 0xff, (size_t)Nc * P * 4));
@@ -111,6 +126,14 @@ int main(int argc, char** argv) {
     bad = 0;
     for (size_t i = 0; i < ref.size(); ++i) bad += memcmp(&ref[i], &got[i], 4) != 0;
     printf("   128-row tiles vs 256-row tiles: %zu of %zu words differ\n", bad, ref.size());
+    gemmx2h_tune_set("x2_rows128", 3);
+    CK(hipMemset(r0, 0xff, (size_t)Nc * P * 4));
+    ep.o0 = r0; CK(launch_gemmx2h_nt(0, EPI_STORE, A, P, Bx2, Nc, P, P, ep));
+    gemmx2h_tune_set("x2_rows128", 0);
+    CK(hipMemcpy(ref.data(), r0, ref.size() * 4, hipMemcpyDeviceToHost));
+    bad = 0;
+    for (size_t i = 0; i < ref.size(); ++i) bad += memcmp(&ref[i], &got[i], 4) != 0;
+    printf("   weight ring of 3 vs default: %zu of %zu words differ\n", bad, ref.size());
     gemmx2h_tune_set("x2_rows128", 2);
     CK(hipMemset(r0, 0xff, (size_t)Nc * P * 4));
     ep.o0 = r0; CK(launch_gemmx2h_nt(0, EPI_STORE, A, P, Bx2, Nc, P, P, ep));
@@ -157,6 +180,23 @@ int main(int argc, char** argv) {
       // probe (results wrong): the loaded 32 bytes used as the fp16 fragments themselves (a producer-side split)
       {"x2h store, A pre-split [probe]", 2, EPI_STORE, 0, 2001}, {"x2h gabor_fwd, A pre-split [probe]", 2, EPI_GABOR_FWD, 0, 2001},
       {"x2h fwd no out, A pre-split [probe]", 2, EPI_GABOR_FWD, 2, 2001}, {"x2h gabor_bwd rec, A pre-split [probe]", 2, EPI_GABOR_BWD, 1, 2001},
+      // A through LDS in whole cache lines (8 rows x 128 B per DMA instruction, source-side swizzle): bit-identical
+      {"x2h store (LDS, whole lines)", 2, EPI_STORE, 0, 2}, {"x2h gabor_fwd (LDS, whole lines)", 2, EPI_GABOR_FWD, 0, 2},
+      {"x2h gabor_bwd rec (LDS, whole lines)", 2, EPI_GABOR_BWD, 1, 2}, {"x2h fwd no out (LDS, whole lines)", 2, EPI_GABOR_FWD, 2, 2},
+      // weight pieces two stages ahead in a ring of three buffers (bit-identical)
+      {"x2h store (weight ring 3)", 2, EPI_STORE, 0, 301}, {"x2h gabor_fwd (weight ring 3)", 2, EPI_GABOR_FWD, 0, 301},
+      {"x2h gabor_bwd rec (weight ring 3)", 2, EPI_GABOR_BWD, 1, 301}, {"x2h fwd no out (weight ring 3)", 2, EPI_GABOR_FWD, 2, 301},
+      // probes (results wrong): the stage-end synchronisation taken out
+      {"x2h store, no load wait [probe]", 2, EPI_STORE, 0, 3001}, {"x2h store, no barrier [probe]", 2, EPI_STORE, 0, 4001},
+      {"x2h store, no wait no barrier [probe]", 2, EPI_STORE, 0, 5001}, {"x2h gabor_fwd, no wait no barrier [probe]", 2, EPI_GABOR_FWD, 0, 5001},
+      {"x2h gabor_bwd rec, no wait no barrier [probe]", 2, EPI_GABOR_BWD, 1, 5001},
+      {"x2h store, loads not waited for [probe]", 2, EPI_STORE, 0, 6001}, {"x2h gabor_fwd, loads not waited for [probe]", 2, EPI_GABOR_FWD, 0, 6001},
+      {"x2h fwd no out, loads not waited for [probe]", 2, EPI_GABOR_FWD, 2, 6001},
+      {"x2h store, loads (to a register) not waited for [probe]", 2, EPI_STORE, 0, 7001},
+      {"x2h store (LDS), whole-line DMA pieces [probe]", 2, EPI_STORE, 0, 9000}, {"x2h gabor_fwd (LDS), whole-line DMA [probe]", 2, EPI_GABOR_FWD, 0, 9000},
+      {"x2h fwd no out (LDS), whole-line DMA [probe]", 2, EPI_GABOR_FWD, 2, 9000},
+      {"x2h store, A = tile 0 for all (L2 hits, real pattern) [probe]", 2, EPI_STORE, 0, 8001},
+      {"x2h fwd no out, A = tile 0 for all [probe]", 2, EPI_GABOR_FWD, 2, 8001},
       // ablation (results wrong): every row of A is row 0 -> all A loads hit the caches
       {"x2h store (LDS), A cached [abl]", 2, EPI_STORE, 0, 10}, {"x2h store (regs), A cached [abl]", 2, EPI_STORE, 0, 11},
   };
@@ -169,9 +209,10 @@ int main(int argc, char** argv) {
       ep.omega = 20.f; ep.scale = 30.f; ep.kvalid = P / 2;
       ep.recompute_out = V.recompute == 1;
       ep.amax_a = slots; ep.amax_b = slots + 64; ep.amax_out = slots + 192;
-      ep.stagger = V.amode >= 2000 ? 778 : (V.amode >= 1000 ? 777 : 0);
+      if (V.amode >= 7000) ep.kvalid = -783;
+      ep.stagger = V.amode >= 9000 ? 785 : V.amode >= 8000 ? 784 : V.amode >= 6000 ? 782 : V.amode >= 5000 ? 781 : V.amode >= 4000 ? 780 : V.amode >= 3000 ? 779 : V.amode >= 2000 ? 778 : (V.amode >= 1000 ? 777 : 0);
       gemmx2h_tune_set("x2_amode", V.amode % 10);
-      gemmx2h_tune_set("x2_rows128", V.amode >= 1000 ? 0 : (V.amode >= 200 ? 2 : (V.amode >= 100 ? 1 : 0)));
+      gemmx2h_tune_set("x2_rows128", V.amode >= 1000 ? 0 : (V.amode >= 300 ? 3 : (V.amode >= 200 ? 2 : (V.amode >= 100 ? 1 : 0))));
       const int lda = (V.amode >= 10 && V.amode < 100) ? 0 : P;
       CK(hipEventRecord(e0, 0));
       for (int q = 0; q < 4; ++q) {
@@ -184,6 +225,33 @@ int main(int argc, char** argv) {
       ms /= 4;
       if (r > 0) { sum[v] += ms; if (ms < best[v]) best[v] = ms; }
     }
+  }
+  // ---- who pays for the HBM reads?  The store GEMM with every A row served from cache (no HBM read of A) on one stream,
+  // a plain streaming read of A's 0.54 GB by OTHER waves on a second stream, each alone and both at once: if the pair takes
+  // what the cached GEMM takes alone, HBM traffic is cheap when the MFMA waves do not issue it themselves; if it takes what
+  // the real GEMM takes (A via HBM), the bytes cost the same whoever moves them
+  {
+    hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+    GemmEpiParams ep; ep.ld0 = P; ep.ld1 = P; ep.amax_a = slots; ep.amax_b = slots + 64; ep.o0 = o0;
+    gemmx2h_tune_set("x2_amode", 1); gemmx2h_tune_set("x2_rows128", 0);
+    const size_t n4 = (size_t)N * P / 4;
+    auto wall = [&](int what) {
+      CK(hipDeviceSynchronize());
+      hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int q = 0; q < 4; ++q) {
+        if (what & 1) CK(launch_gemmx2h_nt(s1, EPI_STORE, A, (what & 4) ? P : 0, Bx2, N, P, P, ep));
+        if (what & 2) hipLaunchKernelGGL(stream_read_kernel, dim3(2048), dim3(256), 0, s2, (const float4*)lin, r0, n4);
+      }
+      CK(hipDeviceSynchronize());
+      (void)a; (void)b;
+      return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / 4;
+    };
+    double best[8]; for (double& x : best) x = 1e30;
+    for (int r = 0; r < rounds + 1; ++r)
+      for (int w : {1, 2, 3, 5, 7}) { const double t = wall(w); if (r > 0 && t < best[w]) best[w] = t; }
+    printf("  [who pays] store GEMM, A cached: %.3f ms | stream read of 0.54 GB alone: %.3f ms | both at once: %.3f ms | "
+           "store GEMM, A from HBM: %.3f ms | that + the stream read: %.3f ms\n", best[1], best[2], best[3], best[5], best[7]);
   }
   // ---- does the 256 MiB Infinity Cache pay for a chunk-major schedule?  Two chained store GEMMs (A -> o0 -> o1), layer by
   // layer over all rows against chunk by chunk (each chunk's o0 slice is consumed right after it was produced)

@@ -141,6 +141,7 @@ extern "C" int wire_tune_get(const char* key) {
   if (!strcmp(key, "x3_tn16")) return gemmx3_tn16_mode();
   if (!strcmp(key, "recompute_out")) return g_recompute_out;
   if (!strcmp(key, "split_f16")) return g_split_f16;
+  if (gemmx2h_tune_get(key) >= 0) return gemmx2h_tune_get(key);
   return fail(WIRE_ERR_ARG, "unknown tuning key: %s", key);
 }
 extern "C" int wire_tune_set(const char* key, int value) {

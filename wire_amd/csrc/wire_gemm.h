@@ -127,6 +127,7 @@ hipError_t launch_x2_split_b_batch(hipStream_t s, const X2SplitBatch& sb, int nb
 hipError_t launch_gemmx2h_nt(hipStream_t s, int epi, const float* A, int lda, const void* Bx2, int64_t M, int Nc,
                              int Kd, const GemmEpiParams& ep);
 int gemmx2h_tune_set(const char* key, int value);
+int gemmx2h_tune_get(const char* key);     // "x2_amode" -> value; -1 = unknown key
 bool gemmx2_tn_applies(int Pm, int Pn);
 int gemmx2_tn_splits(int64_t n, int Pm, int Pn, int max_splits);
 hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n, int Pm,

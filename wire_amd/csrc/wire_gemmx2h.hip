@@ -141,11 +141,15 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
                                                             const unsigned short* __restrict__ Bx2, int M, int Nc,
                                                             int Kd, int tiles_m, int tiles_n, GemmEpiParams ep) {
   static_assert(NRB == 4 || AMODE == 1, "the 128-row tile loads A straight into registers");
-  static_assert(PFD == 1 || (PFD == 2 && NRB == 2 && AMODE == 1), "two stages of prefetch: 128-row tile, A in registers");
-  static_assert(!APRE || (AMODE == 1 && NRB == 4 && PFD == 1), "pre-split A: the default edition only");
+  // PFD = 3 (NRB 4, AMODE 1): the WEIGHT pieces two stages ahead in a ring of three stage buffers (80 KB of LDS, still two
+  // workgroups per CU), the rows one stage ahead as with PFD = 1: the stage-end barrier then never waits for a weight piece
+  static_assert(PFD == 1 || (PFD == 2 && NRB == 2 && AMODE == 1) || (PFD == 3 && NRB == 4 && AMODE == 1),
+                "two stages of prefetch: 128-row tile, A in registers; weight ring: the default tile");
+  constexpr bool BRING = PFD == 3;
+  static_assert(!APRE || ((AMODE == 1 || AMODE == 2) && NRB == 4 && PFD == 1), "pre-split A: the 256-row editions only");
   constexpr int A_LDS = NRB == 4 ? X2_ABYTES : 0;      // (AMODE 1 at NRB 4: this part only serves the epilogues' reductions)
   constexpr int TBM = 64 * NRB;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[A_LDS + (PFD + 1) * X2_BSTAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[A_LDS + (PFD == 1 ? 2 : 3) * X2_BSTAGE];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -175,9 +179,51 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
       int row = m_base + wave * (16 * NRB) + rb * 16 + r;
       row = row < M ? row : M - 1;
       a_off[rb] = (unsigned)(row - m_base) * (unsigned)lda * 4u + (unsigned)(ksl * 32 + hq * 16);
+#ifdef WIRE_X2_TILED_PROBE
+      // timing probe (results wrong; AMODE 0): 785 -> a DMA instruction fetches 8 rows x 128 bytes (whole cache lines, each
+      // touched by ONE instruction) instead of 16 rows x 64 bytes (half lines, each line touched by two)
+      if (ep.stagger == 785) {
+        int row8 = m_base + wave * (16 * NRB) + rb * 16 + (lane >> 3);
+        row8 = row8 + 8 < M ? row8 : (M > 8 ? M - 9 : 0);     // (harness shapes only: the last tile has >= 9 rows)
+        row8 = row8 < m_base ? m_base : row8;
+        a_off[rb] = (unsigned)(row8 - m_base) * (unsigned)lda * 4u + (unsigned)((lane & 7) * 16);
+      }
+#endif
     }
   }
+#ifdef WIRE_X2_TILED_PROBE
+  const unsigned a_second = ep.stagger == 785 ? 8u * (unsigned)lda * 4u : 64u;
+#else
+  constexpr unsigned a_second = 64u;
+#endif
+  // AMODE 2: the same wave-private region filled in WHOLE CACHE LINES -- a DMA instruction fetches 8 rows x 128 bytes (lane =
+  // (row l >> 3, 16-byte chunk), each line touched by exactly one instruction) instead of 16 rows x 64 bytes (each line
+  // touched by two): half the line requests on the vector-memory path for the same bytes (profiles/r03_gemm_x2_whole_line.txt:
+  // - 14 % per launch).  The image is lane-linear ([row][8 slots of 16 B]), so the bank swizzle sits on the SOURCE: slot p of
+  // row r holds chunk p ^ sw(r), sw(r) = bit 1 of r | bit 3 of r << 2.  A fragment read (lane = row r, k slot ks: chunks 2 ks
+  // and 2 ks + 1 at slots (2 ks) ^ sw, (2 ks + 1) ^ sw) is conflict-free: a ds_read_b128 lane group holds the 16 rows with
+  // k slots that differ by one between rows {0-3, 12-15} and {4-11} (chunks differ by XOR 2), the 16-byte bank slot of a
+  // lane is 8 (r & 1) + slot, and within either parity of r the four rows of each set get four different sw with bit 1 clear.
+  unsigned a_off2[NRB][2];
+  if constexpr (AMODE == 2) {
+    const int rr = lane >> 3, pp = lane & 7;
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int row = m_base + wave * (16 * NRB) + rb * 16 + 8 * j + rr;
+        row = row < M ? row : M - 1;
+        const int sw = ((rr >> 1) & 1) | (j << 2);
+        a_off2[rb][j] = (unsigned)(row - m_base) * (unsigned)lda * 4u + (unsigned)((pp ^ sw) * 16);
+      }
+  }
+#ifdef WIRE_X2_TILED_PROBE
+  // timing probe (results wrong): 784 -> every workgroup reads the rows of tile 0 -- the real access pattern (16 lines per
+  // load instruction, every lane its own row), served by the L2 instead of HBM
+  const char* const a_tile = reinterpret_cast<const char*>(A + (ep.stagger == 784 ? (size_t)0 : (size_t)m_base * lda));
+#else
   const char* const a_tile = reinterpret_cast<const char*>(A + (size_t)m_base * lda);
+#endif
   // B: the 16 KB of a stage lie in the image as they do in LDS: piece q = wave + 4 j, 1 KB each
   const char* const b_tile = reinterpret_cast<const char*>(Bx2) + (size_t)ct * nk * X2_BSTAGE;
   const unsigned b_off = (unsigned)(wave * 1024 + lane * 16);
@@ -218,7 +264,14 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
 #pragma unroll
       for (int rb = 0; rb < NRB; ++rb) {
         x2_dma16(ab + a_off[rb], a_lds + rb * 2048);
-        x2_dma16(ab + a_off[rb] + 64, a_lds + rb * 2048 + 1024);
+        x2_dma16(ab + a_off[rb] + a_second, a_lds + rb * 2048 + 1024);
+      }
+    }
+    if constexpr (AMODE == 2) {
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+        x2_dma16(ab + a_off2[rb][0], a_lds + rb * 2048);
+        x2_dma16(ab + a_off2[rb][1], a_lds + rb * 2048 + 1024);
       }
     }
     const char* bb = b_tile + (size_t)kt * X2_BSTAGE;
@@ -236,6 +289,11 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
   // fragment addresses: A block rb: lane (row r = lane & 15, k slot ks = lane >> 4) reads its 32 bytes as two 16-byte
   // pieces at [ks][0][r], [ks][1][r]; B block cb of a plane: lane * 16
   const int a_rd = wave * X2_AWAVE + (lane >> 4) * 512 + (lane & 15) * 16;
+  // AMODE 2: row r of the block at (r >> 3) * 1024 + (r & 7) * 128, chunks 2 ks and 2 ks + 1 at the swizzled slots
+  const int a2_sw = (((lane & 15) >> 1) & 1) | ((((lane & 15) >> 3) & 1) << 2);
+  const int a2_row = wave * X2_AWAVE + ((lane & 15) >> 3) * 1024 + (lane & 7) * 128;
+  const int a2_rd0 = a2_row + (((lane >> 4) * 2) ^ a2_sw) * 16;
+  const int a2_rd1 = a2_row + (((lane >> 4) * 2 + 1) ^ a2_sw) * 16;
   const int b_rd = A_LDS + lane * 16;
   // the last column tile of a width that is no multiple of 128 (K = 212: 448) has 64 columns: skip the idle half
   const bool half_tile = Nc - n_base <= 64;
@@ -308,17 +366,26 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
   }
 
   issue(0, 0);
+  if constexpr (BRING) { if (nk > 1) issue(1, 1); }
   if constexpr (AMODE == 1) aload(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   int buf = 0;
+#ifdef WIRE_X2_TILED_PROBE
+  f32x4 adummy = {0.f, 0.f, 0.f, 0.f};
+#endif
   for (int kt = 0; kt < nk; ++kt) {
-    if constexpr (AMODE == 0) {
+    if constexpr (AMODE == 0 || AMODE == 2) {
 #pragma unroll
       for (int rb = 0; rb < NRB; ++rb) {
-        araw[rb][0] = *reinterpret_cast<const f32x4*>(smem + a_rd + rb * 2048);
-        araw[rb][1] = *reinterpret_cast<const f32x4*>(smem + a_rd + rb * 2048 + 256);
+        if constexpr (AMODE == 2) {
+          araw[rb][0] = *reinterpret_cast<const f32x4*>(smem + a2_rd0 + rb * 2048);
+          araw[rb][1] = *reinterpret_cast<const f32x4*>(smem + a2_rd1 + rb * 2048);
+        } else {
+          araw[rb][0] = *reinterpret_cast<const f32x4*>(smem + a_rd + rb * 2048);
+          araw[rb][1] = *reinterpret_cast<const f32x4*>(smem + a_rd + rb * 2048 + 256);
+        }
       }
       // the region is refilled right away: every read of it must have returned
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -358,6 +425,41 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
     if constexpr (AMODE == 1) {
       // the raw registers are free again: next stage's rows and weight pieces go out under this stage's MFMAs
       __builtin_amdgcn_sched_barrier(0);
+#ifdef WIRE_X2_TILED_PROBE
+      // timing probe (results wrong): the rows of the next stage are loaded as always but into registers nothing waits
+      // for before the end of the loop -- every stage computes on the rows of stage 0: the loop with its memory traffic
+      // and without its dependence on it
+      if (ep.stagger == 782) {
+        if (kt + 1 < nk) {
+          issue(kt + 1, buf ^ 1);
+          // (by LDS-DMA into the wave's idle 8 KB: no register is the target of a load nobody waits for)
+          const char* ab = a_tile + (size_t)(kt + 1) * a_step;
+          if constexpr (NRB == 4) {
+            if (ep.kvalid == -783) {
+              // ... or into ONE register quad that stays live ("+v": the allocator must not hand it to anything else while
+              // loads are in flight into it); in-order returns make the overwrites harmless
+#pragma unroll
+              for (int rb = 0; rb < NRB; ++rb) {
+                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(adummy) : "v"(ab + g_off[rb]) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(adummy) : "v"(ab + g_off[rb] + 16) : "memory");
+              }
+            } else {
+#pragma unroll
+              for (int rb = 0; rb < NRB; ++rb) {
+                x2_dma16(ab + g_off[rb], a_lds + rb * 2048);
+                x2_dma16(ab + g_off[rb] + 16, a_lds + rb * 2048 + 1024);
+              }
+            }
+          }
+        }
+      } else
+#endif
+      if constexpr (BRING) {
+        // rows of the next stage first, then the weight pieces of the one after: the stage-end wait leaves those 4 in flight
+        if (kt + 1 < nk) aload(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) issue(kt + 2, buf == 0 ? 2 : buf - 1);
+      } else
       if (kt + 1 < nk) { issue(kt + 1, buf ^ 1); aload(kt + 1); }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -383,11 +485,30 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef WIRE_X2_TILED_PROBE
+    // timing probes (results wrong): 779 no wait for the stage's loads, 780 no workgroup barrier, 781 neither
+    if (ep.stagger == 782) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); __builtin_amdgcn_s_barrier(); }   // the weight pieces only
+    else if (ep.stagger == 779) { __builtin_amdgcn_s_barrier(); }
+    else if (ep.stagger == 780) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    else if (ep.stagger == 781) { }
+    else
+#endif
+    {
+    if (BRING && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    }
     __builtin_amdgcn_sched_barrier(0);
-    buf ^= 1;
+    if constexpr (BRING) buf = buf == 2 ? 0 : buf + 1; else buf ^= 1;
   }
+#ifdef WIRE_X2_TILED_PROBE
+  if (ep.stagger == 782) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(adummy));
+    if (adummy[0] == 123.456f) acc[0][0][0] += adummy[1];
+    __builtin_amdgcn_s_barrier();           // (the epilogues reuse this LDS)
+  }
+#endif
   h_epilogue<EPI, true, NRB>(acc, ep, M, m_base + wave * (16 * NRB), n_base, Nc, lane, smem, wave, rt, inv_a * inv_b);
 }
 
@@ -400,13 +521,20 @@ static int x2_env(const char* name, int dflt) {
 // and dropped (profiles/r03_gemm_x2_prefetch_ablation.txt): an L2 prefetch of the rows three stages ahead (+ 0.02 ms: the
 // cost of the HBM reads is not their latency -- with every A row served from cache the store form takes 0.347 ms, i.e. the
 // 0.54 GB of A cost 0.105 ms, what they cost at 5 TB/s beside a matrix pipe that shares the chip's power budget).
-static std::atomic<int> g_x2_amode{x2_env("WIRE_X2_AMODE", 1)};
+// Round 3, late: A through the wave-private LDS region in WHOLE cache lines (AMODE 2, default): 0.382 / 0.496 / 0.519 ms -- the
+// half-line pieces of AMODE 0 and the fragment-shaped register loads of AMODE 1 (16 rows x 64 bytes per instruction) put
+// twice the line requests on the vector-memory path for the same bytes (profiles/r03_gemm_x2_whole_line.txt).
+static std::atomic<int> g_x2_amode{x2_env("WIRE_X2_AMODE", 2)};
 // 128-row tiles (3 workgroups per CU) for every epilogue but the first-layer data gradients, whose per-tile sums are laid
 // out for 256-row tiles.  "x2_rows128" / WIRE_X2_ROWS128.
 static std::atomic<int> g_x2_rows128{x2_env("WIRE_X2_ROWS128", 0)};
+int gemmx2h_tune_get(const char* key) {
+  if (!strcmp(key, "x2_amode")) return g_x2_amode;
+  return -1;
+}
 int gemmx2h_tune_set(const char* key, int value) {
-  if (!strcmp(key, "x2_amode") && (value == 0 || value == 1)) { g_x2_amode = value; return 0; }
-  if (!strcmp(key, "x2_rows128") && value >= 0 && value <= 2) { g_x2_rows128 = value; return 0; }
+  if (!strcmp(key, "x2_amode") && value >= 0 && value <= 2) { g_x2_amode = value; return 0; }
+  if (!strcmp(key, "x2_rows128") && value >= 0 && value <= 3) { g_x2_rows128 = value; return 0; }
   return -1;
 }
 
@@ -417,7 +545,7 @@ static hipError_t launchx2h_t(hipStream_t s, const float* A, int lda, const unsi
   // the 128-row editions (three workgroups per CU; optionally two stages of prefetch) are bit-identical and measured no
   // faster (profiles/r03_gemm_x2_rows128.txt, r03_gemm_x2_prefetch2.txt): they are compiled into the harness build only
 #ifdef WIRE_X2_EXPERIMENTS
-  const bool small = g_x2_rows128 != 0 && EPI != EPI_GABOR_BWD_FIRST && EPI != EPI_GABOR2D_BWD_FIRST && !ep.cr_partial &&
+  const bool small = g_x2_rows128 != 0 && g_x2_rows128 != 3 && EPI != EPI_GABOR_BWD_FIRST && EPI != EPI_GABOR2D_BWD_FIRST && !ep.cr_partial &&
                      ep.a_split_inv == 0.f;
 #else
   const bool small = false;
@@ -438,19 +566,29 @@ static hipError_t launchx2h_t(hipStream_t s, const float* A, int lda, const unsi
       return hipGetLastError();
     }
   }
+  if (g_x2_rows128 == 3 && ep.a_split_inv == 0.f) {       // weight ring of three stages on the default tile
+    hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 1, 4, 3>), grid, dim3(256), 0, s, A, lda, Bx2, (int)M, Nc, Kd, tiles_m, tiles_n, ep);
+    return hipGetLastError();
+  }
 #endif
   if (ep.a_split_inv != 0.f) {
     // (only the forward forms read an activation; the data gradients read g_lin, which has no a-priori bound)
     if constexpr (EPI == EPI_STORE || EPI == EPI_GABOR_FWD || EPI == EPI_GABOR2D_FWD || EPI == EPI_SIREN_FWD ||
                   EPI == EPI_GAUSS_FWD) {
-      hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 1, 4, 1, true>), grid, dim3(256), 0, s, A, lda, Bx2, (int)M, Nc, Kd, tiles_m,
-                         tiles_n, ep);
+      if (g_x2_amode == 2)
+        hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 2, 4, 1, true>), grid, dim3(256), 0, s, A, lda, Bx2, (int)M, Nc, Kd, tiles_m,
+                           tiles_n, ep);
+      else
+        hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 1, 4, 1, true>), grid, dim3(256), 0, s, A, lda, Bx2, (int)M, Nc, Kd, tiles_m,
+                           tiles_n, ep);
       return hipGetLastError();
     } else {
       return hipErrorInvalidValue;
     }
   }
-  if (g_x2_amode == 1)
+  if (g_x2_amode == 2)
+    hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 2, 4>), grid, dim3(256), 0, s, A, lda, Bx2, (int)M, Nc, Kd, tiles_m, tiles_n, ep);
+  else if (g_x2_amode == 1)
     hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 1, 4>), grid, dim3(256), 0, s, A, lda, Bx2, (int)M, Nc, Kd, tiles_m, tiles_n, ep);
   else
     hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 0, 4>), grid, dim3(256), 0, s, A, lda, Bx2, (int)M, Nc, Kd, tiles_m, tiles_n, ep);
