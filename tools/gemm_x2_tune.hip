@@ -183,6 +183,8 @@ int main(int argc, char** argv) {
       // A through LDS in whole cache lines (8 rows x 128 B per DMA instruction, source-side swizzle): bit-identical
       {"x2h store (LDS, whole lines)", 2, EPI_STORE, 0, 2}, {"x2h gabor_fwd (LDS, whole lines)", 2, EPI_GABOR_FWD, 0, 2},
       {"x2h gabor_bwd rec (LDS, whole lines)", 2, EPI_GABOR_BWD, 1, 2}, {"x2h fwd no out (LDS, whole lines)", 2, EPI_GABOR_FWD, 2, 2},
+      // the same bytes (lin + out written) with cheaper epilogue arithmetic: max(lin, 0) / one sine per element
+      {"x2h relu_fwd (LDS, whole lines)", 2, EPI_RELU_FWD, 0, 2}, {"x2h siren_fwd (LDS, whole lines)", 2, EPI_SIREN_FWD, 0, 2},
       // weight pieces two stages ahead in a ring of three buffers (bit-identical)
       {"x2h store (weight ring 3)", 2, EPI_STORE, 0, 301}, {"x2h gabor_fwd (weight ring 3)", 2, EPI_GABOR_FWD, 0, 301},
       {"x2h gabor_bwd rec (weight ring 3)", 2, EPI_GABOR_BWD, 1, 301}, {"x2h fwd no out (weight ring 3)", 2, EPI_GABOR_FWD, 2, 301},
