@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
   if (rt >= tiles_m) return;
   const int m_base = rt * TBM, n_base = ct * X2_TBN;
   const int nk = Kd / X2_BK;
+
   // operand scales from the producers' maxima (uniform; a kernel boundary lies between the producers and this read)
   float s_a, inv_a, s_b, inv_b;
   if constexpr (APRE) { s_a = 1.f; inv_a = ep.a_split_inv; }
