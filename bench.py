@@ -163,6 +163,25 @@ def alg_flops(kind, K, Ln, Din, On):
     return 6 * K * K * Ln + 4 * Din * K + 6 * K * On
 
 
+def alg_hbm_bytes(kind, K, Ln):
+    """Algorithmic HBM bytes per sample of a training step of a REAL net (siren / gauss / relu; P = padded width) on this
+    dataflow -- every activation written once and read by exactly the kernels that need it:
+    first layer 2 P (lin_0, out_0; relu: out_0 only); hidden layer forward P read + lin_l + out_l written (the last layer's out
+    is not stored; relu stores no lin); fused final stage P read + P written; weight gradient 2 P; data gradient 2 P read + P
+    written (layer 1 writes nothing: its epilogue forms the first layer's sums).  These nets are HBM-bound: this is their
+    roofline, the MFMA fraction beside it is for comparison with the wire numbers."""
+    if kind not in ("siren", "gauss", "relu"):
+        return None
+    P = (K + 63) // 64 * 64
+    relu = kind == "relu"
+    floats = (1 if relu else 2) * P                                   # first layer
+    floats += Ln * P + (0 if relu else Ln * P) + (Ln if relu else Ln - 1) * P   # forward: reads, lin, out
+    floats += 2 * P                                                   # final stage
+    floats += Ln * 2 * P                                              # weight gradients
+    floats += Ln * 2 * P + (Ln - 1) * P                               # data gradients
+    return 4 * floats
+
+
 def read_prof(lib):
     ms = (C.c_double * 4)()
     cnt = (C.c_int64 * 4)()
@@ -217,6 +236,12 @@ def timed_config(dev, lib, kind, side, hf, steps, warmup=2, **kw):
            "whole_step_frac_of_fp32_mfma_peak": n / dt * F / 1e12 / PEAK_FP32_MFMA_TFLOPS,
            "dominant_gemm": {"class": ["forward", "data gradient", "weight gradient"][klass],
                              "avg_launch_ms": avg_ms, "alg_tflops": gemm_tf, "frac": gemm_tf / peak, "peak": peak}}
+    hb = alg_hbm_bytes(kind, K, L)
+    if hb is not None:
+        res["hbm_bound"] = {"alg_bytes_per_sample": hb, "achieved_TBps": n / dt * hb / 1e12,
+                            "frac_of_8TBps_peak": n / dt * hb / 1e12 / 8.0,
+                            "note": "algorithmic bytes of this dataflow / step time; a plain 1 : 2 read : write stream reaches "
+                                    "5.0 - 5.2 TB/s on this chip (profiles/r03_hbm_stream_probe.txt)"}
     del tr, model
     torch.cuda.empty_cache()
     return res
