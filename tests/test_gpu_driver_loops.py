@@ -392,3 +392,41 @@ def test_get_layer_outputs_matches_reference_montages():
             ref = z[f"montage_{tag}_{i}"]
             assert m.shape == ref.shape
             assert np.abs(m - ref).max() <= 2e-4, f"{tag} layer {i}: {np.abs(m - ref).max():.2e}"
+
+
+def test_grad_ready_hook_announces_every_tensor_once_in_backward_order():
+    """wire_train_fwd_bwd_hooked (include/wire_hip.h): the callback runs on the host, inside the call, once per group of
+    parameter tensors whose gradient is final on the stream -- the final linear layer first (modules/wire.py:156-157), the
+    hidden ComplexGaborLayers from the last to the first, the first layer last (the order the autograd backward of
+    modules/wire.py:161-167 produces them) -- and the gradients equal those of the plain call."""
+    import ctypes as C
+    from wire_amd import _lib
+    from wire_amd.modules import models
+    from wire_amd.trainer import FusedTrainer
+    torch.manual_seed(0)
+    model = models.get_INR(nonlin="wire", in_features=2, out_features=3, hidden_features=91, hidden_layers=3,
+                           first_omega_0=7.0, hidden_omega_0=7.0, scale=6.0).cuda()
+    g = torch.Generator().manual_seed(1)
+    tr = FusedTrainer(model, (40, 33), torch.rand(40 * 33, 3, generator=g), lr=0.0)
+    perm = torch.randperm(40 * 33, generator=g).cuda()
+    tr.step(perm)
+    torch.cuda.synchronize()
+    plain = tr.flat_grad.clone()
+    calls = []
+    cb = _lib.GRAD_READY_FN(lambda user, first, n: calls.append((first, n)))
+    L, d = _lib.lib(), C.byref(tr.desc)
+    stream = torch.cuda.current_stream().cuda_stream
+    n = 40 * 33
+    tr.gbuf[0].zero_()
+    _lib.check(L.wire_coords_from_index(stream, perm.data_ptr(), 0, n, tr.tx.data_ptr(), tr.grid[1], tr.ty.data_ptr(),
+                                        tr.grid[0], None, 1, tr.coords.data_ptr()), "coords")
+    _lib.check(L.wire_train_fwd_bwd_hooked(
+        stream, d, tr.packed.data_ptr(), tr.coords.data_ptr(), n, tr.target.data_ptr(), perm.data_ptr(), 0, 1.0,
+        tr.y.data_ptr(), tr.gy.data_ptr(), tr.gbuf[0].data_ptr() + 4 * tr.count, None, tr.partial.data_ptr(),
+        tr.act.data_ptr(), tr.act_bytes, tr.scratch.data_ptr(), tr.scr_bytes, tr.grad_ptrs[0], cb, None), "hooked")
+    torch.cuda.synchronize()
+    nt = len(tr.offsets)                                   # 2 tensors per layer: 1 first + 3 hidden + 1 final = 10
+    assert nt == 10
+    assert calls == [(8, 2), (6, 2), (4, 2), (2, 2), (0, 2)]
+    assert calls == list(tr._ready_order())
+    assert torch.equal(tr.flat_grad, plain)
