@@ -474,6 +474,40 @@ def test_presplit_activations_agree_with_fp32_activations(nonlin, hf, om_sc):
     assert e_y <= 1e-6 and e_g <= 2e-6
 
 
+@pytest.mark.parametrize("nonlin,hf", [("wire", 363), ("wire", 256), ("wire2d", 256), ("siren", 256), ("relu", 256)])
+def test_operand_load_editions_are_bit_identical(nonlin, hf):
+    """Knob "x2_amode" (wire_gemmx2h.hip): how the forward / data-gradient GEMM fetches its activation operand -- 2 (default)
+    through LDS in whole 128-byte lines with the bank swizzle on the source address, 1 straight into fragment registers,
+    0 through LDS in half-line pieces.  The same values reach the same MFMAs in the same order: the training step
+    (modules/wire.py:88-93 forward, its autograd backward) must not change by a bit.  Ragged last tile."""
+    from wire_amd import _lib
+    from wire_amd.modules import models
+    from wire_amd.trainer import FusedTrainer
+    L = _lib.lib()
+    assert L.wire_tune_get(b"x2_amode") == 2
+    res = []
+    for mode in (2, 1, 0):
+        _lib.check(L.wire_tune_set(b"x2_amode", mode))
+        try:
+            torch.manual_seed(3)
+            kw = dict(first_omega_0=20.0, hidden_omega_0=20.0, scale=30.0) if nonlin == "wire" else \
+                dict(first_omega_0=10.0, hidden_omega_0=10.0, scale=10.0) if nonlin == "wire2d" else \
+                dict(first_omega_0=30.0, hidden_omega_0=30.0)
+            model = models.get_INR(nonlin=nonlin, in_features=2, out_features=3, hidden_features=hf, hidden_layers=3,
+                                   **kw).to(DEV)
+            g = torch.Generator().manual_seed(5)
+            N = 96 * 67
+            tr = FusedTrainer(model, (96, 67), torch.rand(N, 3, generator=g), lr=0.0, keep_rec=True)
+            loss = tr.step(torch.randperm(N, generator=g).to(DEV))
+            torch.cuda.synchronize()
+            res.append((loss.clone(), tr.rec.clone(), tr.flat_grad.clone()))
+        finally:
+            _lib.check(L.wire_tune_set(b"x2_amode", 2))
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1]) and torch.equal(res[0][2], other[2])
+    assert float(res[0][2].abs().max()) > 0
+
+
 KIND_CASES = {
     # name: (get_INR kwargs, grid)  -- rows = a few 256-row blocks of the fused final stage plus a ragged one
     "wire": (dict(nonlin="wire", hidden_features=91, first_omega_0=7.0, hidden_omega_0=7.0, scale=6.0), (37, 29)),
