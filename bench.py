@@ -170,6 +170,13 @@ def alg_hbm_bytes(kind, K, Ln):
     is not stored; relu stores no lin); fused final stage P read + P written; weight gradient 2 P; data gradient 2 P read + P
     written (layer 1 writes nothing: its epilogue forms the first layer's sums).  These nets are HBM-bound: this is their
     roofline, the MFMA fraction beside it is for comparison with the wire numbers."""
+    if kind == "wire":
+        # complex rows of P = roundup(2 K, 64) floats: first layer P (out_0); forward P read + lin + out written (the last
+        # layer's out is not stored); final stage 2 P; weight gradient 2 P; data gradient 2 P read + P written, layer 1 reads
+        # g_lin only (u, out_0 re-evaluated from the coordinates) and writes nothing (first-layer sums in its epilogue)
+        P = (2 * K + 63) // 64 * 64
+        floats = P + (2 * Ln * P + (Ln - 1) * P) + 2 * P + Ln * 2 * P + ((Ln - 1) * 3 * P + P)
+        return 4 * floats
     if kind not in ("siren", "gauss", "relu"):
         return None
     P = (K + 63) // 64 * 64
@@ -564,6 +571,11 @@ def main():
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "mfma_busy": mfma_busy, "pmc_source": pmc_note,
                          "avg_launch_ms": avg_ms, "launches": int(cnt[klass]),
+                         "hbm_view": {"alg_bytes_per_step": alg_hbm_bytes("wire", K, L) * n_gpu_batch,
+                                      "achieved_TBps": alg_hbm_bytes("wire", K, L) * n_gpu_batch / (dt / args.steps) / 1e12,
+                                      "note": "the step's algorithmic HBM bytes (every activation written once, read by the "
+                                              "kernels that need it) / step time; a plain 1 : 2 read : write stream reaches "
+                                              "5.0 - 5.2 TB/s on this chip: the GEMM launches are as much HBM- as MFMA-bound"},
                          "alg_flops_per_launch": alg_per_launch,
                          "peak_note": (f"dense f16 / bf16 MFMA peak 2500 TFLOP/s / {nprod} partial products per fp32 product; "
                                        f"executed MFMA rate = {nprod} x achieved; against the 3xbf16 family's 416.7 this is "
