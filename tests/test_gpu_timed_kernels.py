@@ -616,7 +616,7 @@ def test_first_layer_sums_in_epilogue_agree_with_separate_pass(nonlin):
     assert np.array_equal(a[n0:], b[n0:])              # every other gradient is untouched by the knob
 
 
-def test_wide_offsets_beyond_4gib_on_the_32x32_kernels():
+def test_wide_offsets_beyond_4gib():
     """the 32 x 32 x 16 epilogues (wire_gemm_epi.h) switch to 64-bit offsets (`ep.wide`) once a buffer
     passes M * ld * 4 >= 4 GiB -- 2^21 rows of a 256-complex layer.  With the 16 x 16 x 32 editions switched off
     ("x3_h16" = 0) a hidden ComplexGaborLayer (modules/wire.py:88-93) runs those kernels on 2^21 + 4133 rows: forward
@@ -635,9 +635,11 @@ def test_wide_offsets_beyond_4gib_on_the_32x32_kernels():
     gout = torch.view_as_complex(torch.randn(n, 256, 2, generator=g, device=DEV))
     L = _lib.lib()
     res = {}
-    for h16 in (0, 15):
-        _lib.check(L.wire_tune_set(b"x3_h16", h16))
-        _lib.check(L.wire_tune_set(b"split_f16", 0))      # (the 2 x fp16 path needs the 16 x 16 x 32 kernels anyway)
+    # (0: the 32 x 32 x 16 kernels; 15: the 3 x bf16 16 x 16 x 32 ones; 16: the default 2 x fp16 kernels, whose operand
+    #  loads address a 256-row tile with 32-bit offsets from a 64-bit tile base)
+    for h16 in (0, 15, 16):
+        _lib.check(L.wire_tune_set(b"x3_h16", min(h16, 15)))
+        _lib.check(L.wire_tune_set(b"split_f16", 1 if h16 == 16 else 0))
         try:
             model.zero_grad()
             x.grad = None
@@ -662,3 +664,7 @@ def test_wide_offsets_beyond_4gib_on_the_32x32_kernels():
     assert relmax(o32, out64) <= 1e-5
     assert relmax(gx32, gl @ np.conj(W)) <= 2e-5
     assert relmax(gW32, res[15][2]) <= 2e-5 and relmax(gb32, res[15][3]) <= 2e-5
+    o2, gx2, gW2, gb2 = res[16]
+    assert relmax(o2, out64) <= 1e-5
+    assert relmax(gx2, gl @ np.conj(W)) <= 2e-5
+    assert relmax(gW2, res[15][2]) <= 2e-5 and relmax(gb2, res[15][3]) <= 2e-5
