@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Golden vector of the real-image quality gate (BASELINE.json configs[0]; build container only).
 
-    python3 tests/golden/make_psnr_golden.py          # writes tests/golden/psnr_parrot_cfg1.npz  (a few minutes of CPU)
+    python3 tests/golden/make_psnr_golden.py [name [niters]]     # writes tests/golden/<name>.npz; names: SCHEDULES below
+                                                                 # (psnr_parrot_cfg1, 100 epochs: about an hour of CPU)
 
 Runs the loop of the reference's wire_image_denoise.py:104-178 with the REFERENCE's own model (``modules.wire.INR``
 imported from /root/reference, CPU, fp32) on the RGB channels of the image the reference ships,
@@ -36,16 +37,34 @@ import torch
 REF = "/root/reference"
 OUT = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(OUT))
-NITERS = 10
 MAXPOINTS = 256 * 256
-HIDDEN_FEATURES, LAYERS, OMEGA0, SIGMA0, LR = 128, 2, 7.0, 6.0, 5e-3
+LR = 5e-3
+NOISY = "data_noisy/parrot_noisy_T30.0_snr2.png"
+PUBLISHED = "multiscale_results/denoise/T30.0_SNR2/Final/WIRE_s8_o7_LR5e3_E2000_2/Output_img.png"
+# name -> (niters, hidden_features, hidden_layers, omega0, sigma0, image)
+SCHEDULES = {
+    # BASELINE.json configs[0]: 2 hidden x 128 features (K = 90), omega0 = 7, sigma0 = 6; round 4: 100 epochs = 1100 steps.
+    # The fit target is the NOISY image (the clean data/parrot.png is git-ignored upstream), so the PSNR saturates at the
+    # noise floor of that target (about 17 dB).
+    "psnr_parrot_cfg1": (100, 128, 2, 7.0, 6.0, NOISY),
+    # the net of the reference's published denoise result (29.70 dB, 91 587 parameters: .../WIRE_s8_o7_LR5e3_E2000_2/
+    # metrics_table.md:3): 2 hidden x 300 features (K = 212), omega0 = 7, sigma0 = 8, lr 5e-3, on a shorter schedule.  Fit
+    # target: the RECONSTRUCTION that run stored (Output_img.png, 678 x 1020, the one clean parrot image the reference
+    # holds) -- an image this very architecture produced, so the fit reaches the >= 25 dB regime the published number
+    # lives in within tens of epochs.
+    "psnr_parrot_pub2x300": (30, 300, 2, 7.0, 8.0, PUBLISHED),
+}
+NAME = sys.argv[1] if len(sys.argv) > 1 else "psnr_parrot_cfg1"
+NITERS, HIDDEN_FEATURES, LAYERS, OMEGA0, SIGMA0, IMAGE = SCHEDULES[NAME]
+if len(sys.argv) > 2:
+    NITERS = int(sys.argv[2])
 
 sys.modules.setdefault("cv2", types.ModuleType("cv2"))
 sys.path.insert(0, REF)
 sys.path.insert(0, ROOT)
 from modules import utils, wire  # noqa: E402  (the reference's own modules)
 
-torch.set_num_threads(8)
+torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
 
 
 def checksum(a):
@@ -59,7 +78,7 @@ def checksum(a):
 
 def load_image():
     from PIL import Image
-    img = np.asarray(Image.open(os.path.join(REF, "data_noisy", "parrot_noisy_T30.0_snr2.png")))
+    img = np.asarray(Image.open(os.path.join(REF, IMAGE)))
     assert img.dtype == np.uint8 and img.ndim == 3
     return np.ascontiguousarray(img[..., :3])                  # RGB of RGBA
 
@@ -132,7 +151,7 @@ def main():
     out = dict(
         image_u8=u8, niters=np.int64(NITERS), maxpoints=np.int64(MAXPOINTS), hidden_features=np.int64(HIDDEN_FEATURES),
         hidden_layers=np.int64(LAYERS), omega0=np.float64(OMEGA0), sigma0=np.float64(SIGMA0), lr=np.float64(LR),
-        seed=np.int64(0), torch_version=np.array(torch.__version__),
+        seed=np.int64(0), torch_version=np.array(torch.__version__), image_path=np.array(IMAGE),
         losses=np.array(losses, np.float64), mse_epoch=np.array(mse_epoch, np.float64), psnr=np.float64(psnr32),
         losses64=np.array(losses64, np.float64), mse_epoch64=np.array(mse64, np.float64), psnr64=np.float64(psnr64),
         perm_first8=np.stack([q[:8].numpy() for q in perms]), rec_checksum=checksum(rec.numpy()),
@@ -140,8 +159,8 @@ def main():
     for k, v in sd0.items():
         if "omega_0" not in k and "scale_0" not in k:
             out["sd0_checksum__" + k] = checksum(v.numpy())
-    np.savez_compressed(os.path.join(OUT, "psnr_parrot_cfg1.npz"), **out)
-    print(f"PSNR fp32 reference {psnr32:.4f} dB, fp64 twin {psnr64:.4f} dB; wrote psnr_parrot_cfg1.npz")
+    np.savez_compressed(os.path.join(OUT, NAME + ".npz"), **out)
+    print(f"PSNR fp32 reference {psnr32:.4f} dB, fp64 twin {psnr64:.4f} dB; wrote {NAME}.npz")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,97 @@
+"""The whole-net forward as ONE kernel (wire_amd/csrc/wire_fused.hip): forward-only calls -- ``with torch.no_grad():
+model(coords)``, ``FusedTrainer.render`` (modules/volutils.py:124-133, wire_multi_sr.py:215-217) -- of the 256-feature
+real nets and of `wire` at padded widths 192 / 256 / 384 keep the activations in the wave's registers from the coordinates
+to the output.  Replaces ``self.net(coords)`` of modules/siren.py:90-96, gauss.py:71-74, relu.py:124-130,
+wire.py:161-165.
+
+Checked here: against the layer-by-layer kernels on the same weights (knob "fused_fwd" = 0; same split arithmetic, another
+summation order inside an MFMA and another activation scale: agreement to fp32 round-off) and against the numpy fp64
+oracle under the protocol's ``err_build <= 2 err_ref + 1e-6``, at row counts with a ragged last 128-row tile, for every
+shape that has a kernel and for nets with 1, 2, 3 and 4 hidden layers (the accumulator sets alternate between layers).
+"""
+import numpy as np
+import pytest
+import torch
+
+from _util import params_np, relmax, within_ref
+from oracle import wire_oracle as wo
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+CASES = {
+    # name: (get_INR kwargs, hidden_layers)
+    "siren_4x256": (dict(nonlin="siren", hidden_features=256, first_omega_0=30.0, hidden_omega_0=30.0), 4),
+    "gauss_4x256": (dict(nonlin="gauss", hidden_features=256, scale=10.0), 4),
+    "relu_4x256": (dict(nonlin="relu", hidden_features=256), 4),
+    "siren_3x256": (dict(nonlin="siren", hidden_features=256, first_omega_0=30.0, hidden_omega_0=30.0), 3),
+    "gauss_1x256": (dict(nonlin="gauss", hidden_features=256, scale=10.0), 1),
+    "relu_2x256": (dict(nonlin="relu", hidden_features=256), 2),
+    "wire_k181_4x": (dict(nonlin="wire", hidden_features=256, first_omega_0=20.0, hidden_omega_0=20.0, scale=30.0), 4),
+    "wire_k181_classdef": (dict(nonlin="wire", hidden_features=256, first_omega_0=30.0, hidden_omega_0=30.0, scale=10.0), 4),
+    "wire_k128_3x": (dict(nonlin="wire", hidden_features=182, first_omega_0=7.0, hidden_omega_0=7.0, scale=6.0), 3),
+    "wire_k90_2x_cfg1": (dict(nonlin="wire", hidden_features=128, first_omega_0=7.0, hidden_omega_0=7.0, scale=6.0), 2),
+}
+
+
+def _oracle(kind, P, coords, L, om1, om, sc, double):
+    p = wo.cast_params(P, double)
+    rdt = np.float64 if double else np.float32
+    c = coords.astype(rdt)
+    if kind == "wire":
+        return wo.wire_forward(p, c, L, rdt(om1), rdt(om), rdt(sc))
+    return wo.realnet_forward(kind, p, c, L, rdt(om1), rdt(om), rdt(sc), None)
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_fused_forward_vs_layerwise_and_fp64_oracle(case):
+    from wire_amd import _lib
+    from wire_amd.modules import models
+    kw, Ln = CASES[case]
+    kw = dict(kw)
+    kind = kw["nonlin"]
+    torch.manual_seed(2)
+    model = models.get_INR(in_features=2, out_features=3, hidden_layers=Ln, **kw).to(DEV)
+    n = 128 * 70 + 37                                    # >= 4096 rows; ragged last workgroup (37 rows: 2 waves + 5 rows)
+    coords_np = wo.image_coords(512, 512)[::29][:n]
+    assert coords_np.shape[0] == n
+    coords = torch.tensor(coords_np, device=DEV)
+    L = _lib.lib()
+    assert L.wire_tune_get(b"fused_fwd") == 1
+    with torch.no_grad():
+        y_fused = model(coords[None])[0].cpu().numpy()
+        _lib.check(L.wire_tune_set(b"fused_fwd", 0))
+        try:
+            y_layer = model(coords[None])[0].cpu().numpy()
+        finally:
+            _lib.check(L.wire_tune_set(b"fused_fwd", 1))
+    assert not np.array_equal(y_fused, y_layer), "the knob did not switch kernels"
+    P = params_np(model)
+    om1, om, sc = kw.get("first_omega_0", 30.0), kw.get("hidden_omega_0", 30.0), kw.get("scale", 10.0)
+    y64 = _oracle(kind, P, coords_np, Ln, om1, om, sc, True)
+    y32 = _oracle(kind, P, coords_np, Ln, om1, om, sc, False)
+    err_ref = relmax(y32, y64)
+    e_f, e_l = relmax(y_fused, y64), relmax(y_layer, y64)
+    print(f"fused_fwd[{case}]: fused {e_f:.2e}  layer-by-layer {e_l:.2e}  numpy fp32 {err_ref:.2e}  "
+          f"fused vs layer-by-layer {relmax(y_fused, y_layer):.2e}")
+    within_ref(e_f, err_ref, f"fused_fwd[{case}] y")
+    # the two GPU paths do the same arithmetic up to summation order: they agree as well as either agrees with fp64
+    assert relmax(y_fused, y_layer) <= 2 * max(e_f, e_l) + 1e-6
+
+
+def test_fused_render_equals_model_call_and_covers_every_row():
+    """FusedTrainer.render (tiles of 2^20 rows through wire_mlp_fwd with save_for_bwd = 0) runs the fused kernel: same
+    values as the module call, every row written (no stale tile tails), sigmoid variant included."""
+    from wire_amd.modules import models
+    from wire_amd.trainer import FusedTrainer
+    torch.manual_seed(4)
+    model = models.get_INR(nonlin="siren", in_features=2, out_features=3, hidden_features=256, hidden_layers=4,
+                           first_omega_0=30.0, hidden_omega_0=30.0).to(DEV)
+    H, W = 131, 97
+    tr = FusedTrainer(model, (H, W), torch.zeros(H * W, 3), lr=0.0)
+    out = tr.render(tile=5000)                           # 3 tiles, the last one ragged (and < 4096 rows: layer-by-layer)
+    coords = torch.tensor(wo.image_coords(H, W), device=DEV)
+    with torch.no_grad():
+        ref = model(coords[None])[0]
+    assert relmax(out.cpu().numpy(), ref.cpu().numpy()) <= 2e-6
+    assert torch.equal(out[:5000], ref[:5000])           # a tile of the fused kernel == the same rows of one big launch

@@ -243,6 +243,16 @@ STEP_CASES = {
     "img262k_baseline_w20_s30": ((512, 512), 363, 4, 3, 20.0, 30.0),           # BASELINE.json configs[1]
     "vol16k_occupancy_3x300_w20_s10": ((32, 32, 16), 300, 3, 1, 20.0, 10.0),   # wire_occupancy.py:43-44,89-91
     "vol262k_occupancy_4x363_w20_s10": ((64, 64, 64), 363, 4, 1, 20.0, 10.0),  # BASELINE.json configs[2], 1 GPU's share
+    # the CLASS DEFAULTS of modules/wire.py:103-105 (omega0 = 30, sigma0 = 10: activations up to
+    # exp(2.25) = 9.5 -> the pre-split scale 2^11 branch of wire_api.hip: out_split_scale) and omega0 / sigma0 = 3.5 > 3.33
+    # (no a-priori scale: plain fp32 activations + the device-tracked maximum) on the default 2 x fp16 kernels (>= 4096 rows)
+    "img16k_classdef_w30_s10": ((128, 128), 363, 4, 3, 30.0, 10.0),
+    # (omega0 = 30 / sigma0 = 5 itself is no parity case: the numpy fp32 oracle is 0.25 of max |y| away from its own fp64 twin
+    #  there -- activations up to exp(9), error amplification ~ omega0 |W| per layer: no fp32 implementation, the
+    #  reference's included, has a correct digit left; first round-4 GPU run, gpurun_out/r04_newtests.log.  The branch is the
+    #  same at omega0 = 7 / sigma0 = 2: bound exp(3.06) = 21 > 16.)
+    "img16k_tracked_max_w7_s2": ((128, 128), 363, 4, 3, 7.0, 2.0),
+    "img65k_classdef_k181_w30_s10": ((256, 256), 256, 4, 3, 30.0, 10.0),       # get_INR(hidden_features=256): K = 181, P = 384
 }
 
 
@@ -281,7 +291,7 @@ def test_fused_trainer_step_gradients_vs_fp64_oracle(case, tag_prefix=""):
     tag = f"{tag_prefix}step[{case}]"
     err_y_ref = relmax(y32, y64)
     within_ref(relmax(tr.rec.cpu().numpy()[perm.numpy()], y64), err_y_ref, tag + " y")
-    assert abs(float(loss.item()) - l64) <= (2 * abs(l32 - l64) / l64 + 1e-5) * l64
+    assert abs(float(loss.item()) - l64) <= _loss_tolerance(y32, y64, tgt, l32, l64), tag + " loss"
     flat = tr.flat_grad.cpu().numpy()
     names = [k for k in model.state_dict().keys() if "omega_0" not in k and "scale_0" not in k]
     for name, off in zip(names, tr.offsets):
@@ -293,6 +303,89 @@ def test_fused_trainer_step_gradients_vs_fp64_oracle(case, tag_prefix=""):
                                   resid_max=np.abs(y64 - tgt).max())
         else:
             within_ref(relmax(mine, ref), relmax(ref32, ref), f"{tag} grad {name}")
+
+
+def _loss_tolerance(y32, y64, tgt, l32, l64):
+    """Bound on |loss_build - loss_fp64| of the MSE of wire_image_denoise.py:153.  Two parts:
+     * round 1-3: twice the reference arithmetic's own deviation |l32 - l64| plus 1e-5 of the loss -- enough while the
+       per-element output errors are ~1e-6 (the regimes of the reference's scripts);
+     * round 4, added with the class-default case (omega0 = 30, sigma0 = 10: per-element output errors of 2e-2 of the
+       maximum for ANY fp32 implementation) after its first run came out red on the first part alone:
+       the loss error is the SIGNED sum (2 / M) sum_i r_i d_i of residuals r times output errors d, and the fp32 oracle's
+       own value of that sum is one draw that may cancel to nearly nothing (here 5e-7 against a standard deviation of
+       6e-6).  The yardstick for it is its spread: with the oracle's own |d_i| (doubled, the protocol's factor on the
+       forward error) and three standard deviations, 6 (2 / M) sqrt(sum_i r_i^2 d32_i^2).  For the round 1-3 cases this
+       term is < 1e-8 of the loss and changes nothing."""
+    r = (y64 - tgt).astype(np.float64).ravel()
+    d = (y32.astype(np.float64) - y64).ravel()
+    spread = 6.0 * (2.0 / r.size) * float(np.sqrt(np.sum(r * r * d * d)))
+    return 2 * abs(l32 - l64) + 1e-5 * l64 + spread
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json configs[2] on its REAL grid: one GPU's share of the 512^3 occupancy job
+# ---------------------------------------------------------------------------
+def _sphere_target(side, dev):
+    """Synthetic occupancy (thai_statue.mat is not shipped: .gitignore:9 of the reference): indicator of a ball on the
+    grid of utils.get_coords (modules/utils.py:163-176), built on the device slab by slab; row n = (i W + j) T + k."""
+    ax = torch.tensor(np.linspace(-1, 1, side).astype(np.float32), device=dev)
+    target = torch.empty(side ** 3, 1, device=dev)
+    for i0 in range(0, side, 64):
+        yy, xx, zz = torch.meshgrid(ax[i0:i0 + 64], ax, ax, indexing="ij")
+        target[i0 * side * side:(i0 + yy.shape[0]) * side * side, 0] = \
+            ((xx * xx + yy * yy + zz * zz) < 0.5).float().reshape(-1)
+    return target
+
+
+@pytest.mark.parametrize("net", ["baseline_4x363", "reference_3x300"])
+def test_config3_512cubed_share_vs_fp64_oracle(net):
+    """`FusedTrainer(model, (512, 512, 512), target)` -- the 512^3 coordinate tables of
+    utils.get_coords (modules/utils.py:163-176), the 537 MB target on the device, `step_hashed` slices of the epoch's
+    shuffle of 134 217 728 points (wire_occupancy.py:137-158 with the position-keyed permutation) -- on one GPU's share
+    of the 8-GPU batch: 262 144 points of BASELINE.json's 4x256-complex net, 200 000 (the reference's own maxpoints,
+    wire_occupancy.py:45) of the 3x300 net it builds as written (:43-44,89-91).  Checked on exactly those indices: the
+    index slice (numpy twin of the bijection), the generated coordinates (bit-exact), the gathered target and rec
+    scatter, loss and EVERY parameter gradient against the fp64 oracle under `err_build <= 2 err_ref + 1e-6`."""
+    from wire_amd.trainer import FusedTrainer
+    side = 512
+    hf, Ln, B = (363, 4, 262144) if net == "baseline_4x363" else (300, 3, 200000)
+    om, sc = 20.0, 10.0
+    model = _wire_model(Ln, om, sc, hf=hf, D=3, O=1)
+    target = _sphere_target(side, DEV)
+    tr = FusedTrainer(model, (side, side, side), target, lr=0.0, keep_rec=True, coords_style="numpy")
+    del target
+    lin = np.linspace(-1, 1, side)                       # get_coords: fp64 linspace, cast to fp32 at the end
+    P = params_np(model)
+    names = [k for k in model.state_dict().keys() if "omega_0" not in k and "scale_0" not in k]
+    for seed, first in ((0, 0), (3, side ** 3 - B)):     # first and LAST minibatch position of an epoch
+        loss = tr.step_hashed(seed, first=first, count=B)
+        torch.cuda.synchronize()
+        idx = wo.hash_perm(side ** 3, seed, first, B)
+        assert np.array_equal(tr._hidx[:B].cpu().numpy(), idx)
+        k, j, i = idx % side, (idx // side) % side, idx // (side * side)
+        coords = np.stack([lin[j], lin[i], lin[k]], 1).astype(np.float32)      # (x_j, y_i, z_k)
+        assert np.array_equal(tr.coords[:3 * B].view(B, 3).cpu().numpy(), coords)
+        idx_t = torch.tensor(idx, device=DEV)
+        tgt = tr.target[idx_t].cpu().numpy()
+        assert 0.05 < tgt.mean() < 0.6                   # the ball is there: both classes in the batch
+        y64, l64, g64 = wire_oracle_grads_chunked(P, coords, tgt, Ln, om, om, sc, double=True)
+        y32, l32, g32 = wire_oracle_grads_chunked(P, coords, tgt, Ln, om, om, sc, double=False)
+        tag = f"step[cfg3_512cubed_{net}_seed{seed}]"
+        err_y_ref = relmax(y32, y64)
+        within_ref(relmax(tr.rec[idx_t].cpu().numpy(), y64), err_y_ref, tag + " y")
+        assert abs(float(loss.item()) - l64) <= (2 * abs(l32 - l64) / l64 + 1e-5) * l64
+        flat = tr.flat_grad.cpu().numpy()
+        for name, off in zip(names, tr.offsets):
+            ref = wo.as_real_pairs(g64[name]).astype(np.float64).ravel()
+            ref32 = wo.as_real_pairs(g32[name]).astype(np.float64).ravel()
+            mine = flat[off:off + ref.size]
+            if name == f"net.{Ln + 1}.bias":
+                final_bias_within_ref(mine, ref, err_y_ref, np.abs(y64).max(), 1, f"{tag} grad {name}",
+                                      resid_max=np.abs(y64 - tgt).max())
+            else:
+                within_ref(relmax(mine, ref), relmax(ref32, ref), f"{tag} grad {name}")
+    # rows the two minibatches did not touch are still zero in rec (the scatter wrote nothing else)
+    assert int((tr.rec != 0).sum().item()) <= 2 * B
 
 
 # ---------------------------------------------------------------------------
@@ -364,6 +457,12 @@ def test_fused_trainer_step_every_kind_vs_fp64_oracle_at_bench_size(case):
             masks.append((act[off:off + N * K].view(N, K) > 0).cpu().numpy())
     y64, l64, g64 = oracle_grads_chunked(kind, P, coords, tgt, Ln, om1, om, sc, True, nf, relu_masks=masks)
     y32, l32, g32 = oracle_grads_chunked(kind, P, coords, tgt, Ln, om1, om, sc, False, nf, relu_masks=masks)
+    # wire2d at 1 048 576 rows (round 4): the fp32 yardstick's own error depends on ITS summation
+    # order -- the 16 384-row chunks run through sgemm's blocked reduction, the same oracle in 1 024-row chunks is 2 - 5 x
+    # less accurate on the hidden weight gradients, like every GPU family incl. the exact-fp32 MFMA one
+    # (tools/wgrad_order_probe.py, profiles/r04_wgrad_order_probe.txt).  The protocol's assertion stays on the 16 384-row
+    # yardstick; the ratio against the worse of the two orders is logged beside it.
+    g32b = oracle_grads_chunked(kind, P, coords, tgt, Ln, om1, om, sc, False, nf, chunk=1024)[2] if kind == "wire2d" else None
     if masks is not None:
         flips, flipmax = g64.pop("flips"), g64.pop("flip_lin_max")
         g32.pop("flips"), g32.pop("flip_lin_max")
@@ -385,6 +484,10 @@ def test_fused_trainer_step_every_kind_vs_fp64_oracle_at_bench_size(case):
                                   resid_max=np.abs(y64 - tgt).max())
         else:
             within_ref(relmax(mine, ref), relmax(ref32, ref), f"{tag} grad {name}")
+            if g32b is not None:
+                from _util import RATIO_LOG
+                worst = max(relmax(ref32, ref), relmax(wo.as_real_pairs(g32b[name]).astype(np.float64).ravel(), ref))
+                RATIO_LOG.append((f"{tag} grad {name} [worse of two numpy summation orders]", relmax(mine, ref), worst))
 
 
 @pytest.mark.parametrize("nonlin", ["wire", "wire2d", "siren", "gauss"])

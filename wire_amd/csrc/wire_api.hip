@@ -142,6 +142,7 @@ extern "C" int wire_tune_get(const char* key) {
   if (!strcmp(key, "recompute_out")) return g_recompute_out;
   if (!strcmp(key, "split_f16")) return g_split_f16;
   if (gemmx2h_tune_get(key) >= 0) return gemmx2h_tune_get(key);
+  if (fused_tune_get(key) >= 0) return fused_tune_get(key);
   return fail(WIRE_ERR_ARG, "unknown tuning key: %s", key);
 }
 extern "C" int wire_tune_set(const char* key, int value) {
@@ -153,6 +154,7 @@ extern "C" int wire_tune_set(const char* key, int value) {
   if (!strcmp(key, "split_f16")) { g_split_f16 = value ? 1 : 0; return WIRE_OK; }
   if (!strcmp(key, "split_out")) { g_split_out = value ? 1 : 0; return WIRE_OK; }
   if (gemmx2h_tune_set(key, value) == 0) return WIRE_OK;
+  if (fused_tune_set(key, value) == 0) return WIRE_OK;
   if (gemm_tune_set(key, value) == 0) return WIRE_OK;
   if (gemmx3_tune_set(key, value) == 0) return WIRE_OK;
   return fail(WIRE_ERR_ARG, "unknown tuning key or bad value: %s=%d", key, value);
@@ -172,6 +174,7 @@ struct Plan {
   // packed image offsets (floats); index l = 0..L (l = 0 only when first_gemm)
   std::vector<int64_t> off_fwd, off_dg, off_bias, off_fwd_x3, off_dg_x3, off_fwd_3m, off_dg_3m, off_fwd_x2, off_dg_x2;
   int64_t off_wf, off_bf, off_first, off_wamax, total_packed;   // off_wamax: max-|weight| slots, WIRE_AMAX_SLOTS per layer
+  int64_t off_fx;    // k-permuted 2 x fp16 images of the hidden layers for the fused forward (wire_fused.hip), -1 = no such shape
   std::vector<int64_t> tfloats;
 };
 
@@ -238,6 +241,8 @@ int make_plan(const wire_net_desc* d, Plan& p) {
     }
   }
   p.off_wamax = off; off += (int64_t)(p.L + 1) * WIRE_AMAX_SLOTS;
+  p.off_fx = -1;
+  if (!p.first_gemm && p.L >= 1 && fused_fwd_shape(p.kind, p.P)) { p.off_fx = off; off += (int64_t)p.L * fused_b_image_floats(p.P); }
   p.off_wf = off; off += (int64_t)p.O * p.P;
   p.off_bf = off; off += 64;
   p.off_first = off;   // native copies of the first layer's tensors (W0,b0[,V0,c0])
@@ -347,6 +352,20 @@ float out_split_scale(const Plan& p, int64_t n, int l) {
   }
   const int e = ilogb(bound) + 1;
   return ldexpf(1.f, 15 - e);
+}
+// Power-of-two scale with which the fused forward (wire_fused.hip) splits the activations it keeps in registers: from
+// their a-priori bound as above (sine, Gaussian <= 1; Gabor <= exp(w^2 / 4 s^2), accepted up to 16); 0 = none known
+// (relu: the kernel takes each wave's own maximum; Gabor beyond the bound: the layer-by-layer path runs)
+float fused_act_scale(const Plan& p) {
+  if (p.kind == WIRE_KIND_RELU || p.kind == WIRE_KIND_WIRE2D) return 0.f;
+  double bound = 1.0;
+  if (p.kind == WIRE_KIND_WIRE) {
+    if (!(p.s > 0.f)) return 0.f;
+    const double r = (double)p.w / (2.0 * (double)p.s);
+    if (!(r * r <= 2.7725887)) return 0.f;
+    bound = exp(r * r);
+  }
+  return ldexpf(1.f, 15 - (ilogb(bound) + 1));
 }
 int epi_fwd(int kind) {
   switch (kind) {
@@ -467,6 +486,16 @@ extern "C" int wire_pack_params(void* stream, const wire_net_desc* d, const void
       HIPCHK(launch_amax_batch(s, ab, nb, (int64_t)p.Pl * p.P));
       HIPCHK(launch_x2_split_b_batch(s, xf, nb, p.P, p.Pl, p.P));
       HIPCHK(launch_x2_split_b_batch(s, xd, nb, p.Pl, p.P, p.Pl));
+      if (p.off_fx >= 0) {                                 // the fused forward's edition of the forward image
+        FxSplitBatch fx{};
+        for (int i = 0; i < nb; ++i) {
+          const int l = l0 + i;
+          fx.src[i] = packed + p.off_fwd[l];
+          fx.dst[i] = packed + p.off_fx + (int64_t)(l - 1) * fused_b_image_floats(p.P);
+          fx.slots[i] = ab.slots[i];
+        }
+        HIPCHK(launch_fx_split_b_batch(s, fx, nb, p.P, p.P));
+      }
     }
   }
   HIPCHK(launch_pack_final(s, p.kind, (const float*)params[p.ntens - 2],
@@ -494,6 +523,24 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
   hipStream_t s = (hipStream_t)stream;
   float* A = (float*)act;
   const bool x2 = use_x2(p, n);
+  if (!save_for_bwd && do_final && x2) {
+    // forward-only: the whole net in one kernel, activations in registers (wire_fused.hip)
+    const float a_scale = fused_act_scale(p);
+    if (p.off_fx >= 0 && fused_fwd_enabled() && p.O <= 4 && p.L <= 8 && (a_scale != 0.f || p.kind == WIRE_KIND_RELU)) {
+      FusedFwdParams fp;
+      fp.coords = coords; fp.n = n;
+      fp.W0 = packed + first_native_off(p, 0); fp.b0 = packed + first_native_off(p, 1);
+      fp.wimg = reinterpret_cast<const unsigned char*>(packed + p.off_fx);
+      fp.bias = packed + p.off_bias[1]; fp.bias_stride = p.L >= 2 ? p.off_bias[2] - p.off_bias[1] : 0;
+      fp.wamax = reinterpret_cast<const unsigned*>(packed + p.off_wamax) + WIRE_AMAX_SLOTS; fp.wamax_stride = WIRE_AMAX_SLOTS;
+      fp.wf = packed + p.off_wf; fp.bfr = packed + p.off_bf; fp.y = y;
+      fp.D = p.D; fp.K = p.K; fp.L = p.L; fp.O = p.O; fp.w1 = p.w1; fp.w = p.w; fp.s = p.s;
+      fp.a_scale = a_scale; fp.a_scale_inv = a_scale != 0.f ? 1.f / a_scale : 0.f;
+      ProfScope ps(s, 0, 2.0 * n * p.Pl * p.P * p.L);
+      HIPCHK(launch_fused_fwd(s, p.kind, p.P, fp));
+      return WIRE_OK;
+    }
+  }
   unsigned* const amax = reinterpret_cast<unsigned*>(A + a.amax);            // slots of out_l at amax + 64 l
   auto wamax = [&](int l) { return reinterpret_cast<const unsigned*>(packed + p.off_wamax + (int64_t)l * WIRE_AMAX_SLOTS); };
   if (x2) HIPCHK(hipMemsetAsync(amax, 0, (size_t)(p.L + 2) * WIRE_AMAX_SLOTS * sizeof(unsigned), s));

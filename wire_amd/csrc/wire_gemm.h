@@ -133,3 +133,27 @@ int gemmx2_tn_splits(int64_t n, int Pm, int Pn, int max_splits);
 hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n, int Pm,
                             int Pn, int splits, float* slab, float* bslab, const unsigned* amax_g,
                             const unsigned* amax_z, float z_pre_inv = 0.f);
+
+// ---- whole-net forward in one kernel (wire_fused.hip): activations stay in the wave's registers from the coordinates to
+// the output; the hidden layers' weights come from a k-permuted edition of the 2 x fp16 image (same maximum slots)
+#define FX_SPLIT_MAXB 32
+struct FxSplitBatch { const float* src[FX_SPLIT_MAXB]; void* dst[FX_SPLIT_MAXB]; const unsigned* slots[FX_SPLIT_MAXB]; };
+int64_t fused_b_image_floats(int P);                      // floats of one hidden layer's image
+hipError_t launch_fx_split_b_batch(hipStream_t s, const FxSplitBatch& sb, int nb, int ldb, int P);
+struct FusedFwdParams {
+  const float* coords = nullptr; long long n = 0;         // [n][D]
+  const float* W0 = nullptr; const float* b0 = nullptr;   // first layer, native [K][D], [K]
+  const unsigned char* wimg = nullptr;                    // images of layers 1 .. L back to back (fused_b_image_floats each)
+  const float* bias = nullptr; long long bias_stride = 0; // blocked bias of layer l at bias + (l - 1) * bias_stride, [P]
+  const unsigned* wamax = nullptr; int wamax_stride = 0;  // max |W_l| slots of layer l at wamax + (l - 1) * wamax_stride
+  const float* wf = nullptr; const float* bfr = nullptr;  // final linear image [O][P] and bias [O]
+  float* y = nullptr;                                     // [n][O]
+  int D = 0, K = 0, L = 0, O = 0;
+  float w1 = 0.f, w = 0.f, s = 0.f;                       // first omega_0, hidden omega_0, scale_0
+  float a_scale = 0.f, a_scale_inv = 0.f;                 // power-of-two scale of the activations (relu: the wave's own maximum)
+};
+bool fused_fwd_shape(int kind, int P);
+bool fused_fwd_enabled();
+int fused_tune_get(const char* key);                      // "fused_fwd"; -1 = unknown key
+int fused_tune_set(const char* key, int value);
+hipError_t launch_fused_fwd(hipStream_t s, int kind, int P, const FusedFwdParams& fp);

@@ -528,12 +528,18 @@ static std::atomic<int> g_x2_amode{x2_env("WIRE_X2_AMODE", 2)};
 // 128-row tiles (3 workgroups per CU) for every epilogue but the first-layer data gradients, whose per-tile sums are laid
 // out for 256-row tiles.  "x2_rows128" / WIRE_X2_ROWS128.
 static std::atomic<int> g_x2_rows128{x2_env("WIRE_X2_ROWS128", 0)};
+// "x2_tn_rows" / WIRE_X2_TN_ROWS: upper bound on the rows ONE weight-gradient workgroup accumulates sequentially in its fp32
+// accumulators (0 = the fill-the-chip policy of gemmx2_tn_splits alone).  A shorter chain means more row splits, i.e.
+// more slabs for wgrad_reduce_kernel: the knob of the summation-order measurement (tools/wgrad_order_probe.py).
+static std::atomic<int> g_x2_tn_rows{x2_env("WIRE_X2_TN_ROWS", 0)};
 int gemmx2h_tune_get(const char* key) {
   if (!strcmp(key, "x2_amode")) return g_x2_amode;
+  if (!strcmp(key, "x2_tn_rows")) return g_x2_tn_rows;
   return -1;
 }
 int gemmx2h_tune_set(const char* key, int value) {
   if (!strcmp(key, "x2_amode") && value >= 0 && value <= 2) { g_x2_amode = value; return 0; }
+  if (!strcmp(key, "x2_tn_rows") && value >= 0 && (value == 0 || value >= 256)) { g_x2_tn_rows = value; return 0; }
   if (!strcmp(key, "x2_rows128") && value >= 0 && value <= 3) { g_x2_rows128 = value; return 0; }
   return -1;
 }
@@ -924,6 +930,13 @@ int gemmx2_tn_splits(int64_t n, int Pm, int Pn, int max_splits) {
   if (s > max_splits) s = max_splits;
   if (s < 1) s = 1;
   if (n < 1) return s;
+  const int cap_rows = g_x2_tn_rows;                     // bounded accumulation chains: more splits (up to 4096), whatever max_splits
+  if (cap_rows > 0) {
+    int64_t need = (n + cap_rows - 1) / cap_rows;
+    need = (need + 7) / 8 * 8;
+    if (need > 4096) need = 4096;
+    if (need > s) s = (int)need;
+  }
   long long chunk = (n + s - 1) / s;
   chunk = (chunk + 2 * X2T_TK - 1) / (2 * X2T_TK) * (2 * X2T_TK);
   s = (int)((n + chunk - 1) / chunk);
