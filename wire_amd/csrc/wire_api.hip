@@ -486,7 +486,7 @@ extern "C" int wire_pack_params(void* stream, const wire_net_desc* d, const void
       HIPCHK(launch_amax_batch(s, ab, nb, (int64_t)p.Pl * p.P));
       HIPCHK(launch_x2_split_b_batch(s, xf, nb, p.P, p.Pl, p.P));
       HIPCHK(launch_x2_split_b_batch(s, xd, nb, p.Pl, p.P, p.Pl));
-      if (p.off_fx >= 0) {                                 // the fused forward's edition of the forward image
+      if (p.off_fx >= 0 && fused_pre_scale(p.kind, p.w, p.s) > 0.f) {   // the fused forward's edition of the forward image
         FxSplitBatch fx{};
         for (int i = 0; i < nb; ++i) {
           const int l = l0 + i;
@@ -494,7 +494,7 @@ extern "C" int wire_pack_params(void* stream, const wire_net_desc* d, const void
           fx.dst[i] = packed + p.off_fx + (int64_t)(l - 1) * fused_b_image_floats(p.P);
           fx.slots[i] = ab.slots[i];
         }
-        HIPCHK(launch_fx_split_b_batch(s, fx, nb, p.P, p.P));
+        HIPCHK(launch_fx_split_b_batch(s, fx, nb, p.P, p.P, fused_pre_scale(p.kind, p.w, p.s)));
       }
     }
   }
@@ -526,7 +526,8 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
   if (!save_for_bwd && do_final && x2) {
     // forward-only: the whole net in one kernel, activations in registers (wire_fused.hip)
     const float a_scale = fused_act_scale(p);
-    if (p.off_fx >= 0 && fused_fwd_enabled() && p.O <= 4 && p.L <= 8 && (a_scale != 0.f || p.kind == WIRE_KIND_RELU)) {
+    if (p.off_fx >= 0 && fused_fwd_enabled() && p.O <= 4 && p.L <= 8 && (a_scale != 0.f || p.kind == WIRE_KIND_RELU) &&
+        fused_pre_scale(p.kind, p.w1, p.s) > 0.f && fused_pre_scale(p.kind, p.w, p.s) > 0.f) {
       FusedFwdParams fp;
       fp.coords = coords; fp.n = n;
       fp.W0 = packed + first_native_off(p, 0); fp.b0 = packed + first_native_off(p, 1);
@@ -535,7 +536,9 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
       fp.wamax = reinterpret_cast<const unsigned*>(packed + p.off_wamax) + WIRE_AMAX_SLOTS; fp.wamax_stride = WIRE_AMAX_SLOTS;
       fp.wf = packed + p.off_wf; fp.bfr = packed + p.off_bf; fp.y = y;
       fp.D = p.D; fp.K = p.K; fp.L = p.L; fp.O = p.O; fp.w1 = p.w1; fp.w = p.w; fp.s = p.s;
-      fp.a_scale = a_scale; fp.a_scale_inv = a_scale != 0.f ? 1.f / a_scale : 0.f;
+      fp.c_first = fused_pre_scale(p.kind, p.w1, p.s); fp.c_hidden = fused_pre_scale(p.kind, p.w, p.s);
+      fp.k2_first = p.s * p.s * 1.44269502f / (fp.c_first * fp.c_first);
+      fp.k2 = p.s * p.s * 1.44269502f / (fp.c_hidden * fp.c_hidden);
       ProfScope ps(s, 0, 2.0 * n * p.Pl * p.P * p.L);
       HIPCHK(launch_fused_fwd(s, p.kind, p.P, fp));
       return WIRE_OK;

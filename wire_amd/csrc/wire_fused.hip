@@ -26,7 +26,7 @@
 //
 // Arithmetic = the 2 x fp16 split of wire_gemmx2h.hip (three partial products per fp32 product, fp32 accumulate, power-of-two
 // operand scales: the weights' from their maximum slots, the activations' from their a-priori bound or the wave's own
-// maximum), lean hardware-transcendental epilogues for the hidden layers, first_fwd_kernel's precise forms for layer 0.
+// maximum), hardware transcendentals on pre-scaled arguments for every layer (below: "activations from pre-scaled ...").
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -42,10 +42,62 @@ typedef unsigned fx_u32x4 __attribute__((ext_vector_type(4)));
 #define FX_ROWS (16 * FX_WAVES)
 #define FX_LMAX 8                         // hidden layers whose biases fit the LDS table
 #define FX_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#ifndef FX_PFD
+#define FX_PFD 3                          // column blocks by which the weight-fragment LDS reads run ahead of their MFMAs
+#endif
 
+// LDS-DMA of 16 bytes per lane (1 KB per wave instruction) -- as inline assembly, not __builtin_amdgcn_global_load_lds:
+// with the builtin in a loop the compiler's wait-count pass treats every later LDS read as possibly completing out of order
+// and emits `s_waitcnt lgkmcnt(0)` for ALL of them (measured on a 20-line kernel: 14 x lgkmcnt(2) without the builtin, 7 x
+// lgkmcnt(0) with it), which turns a fragment prefetch of two blocks into none.  The stream is synchronised by hand anyway
+// (fx_stage_top: vmcnt + barrier).  M0 (the LDS base of the DMA) is saved and restored around it.
 WIRE_DEVINL void fx_dma16(const void* gsrc, unsigned char* lds_piece) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
+  const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_piece;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(la) : "memory");
+}
+
+// ---- activations from PRE-SCALED pre-activations.  The ablations of the first edition (profiles/r04_fused_ablation.txt)
+// put a third of the kernel's time into the producer's vector instructions (they do not hide under the MFMAs: the chip
+// runs this loop at its power limit), none into the LDS reads.  So the producer is cut to the bone:
+//   * the constant that the activation multiplies its argument with is folded into the weights and the bias when the
+//     image is packed: r = c lin with c = omega0 / 2 pi (sine, Gabor: v_sin / v_cos take revolutions), c = sigma0
+//     sqrt(log2 e) (Gaussian: exp(-(s lin)^2) = exp2(-r^2)), c = 1 (relu).  The accumulation error of r is the same
+//     RELATIVE error as that of lin (same products, same sums, scaled by c), i.e. the same absolute error in the argument of
+//     the sine as the layer-by-layer path's fl(omega0 lin) carries;
+//   * activations bounded by 16 (everything but relu) are split into (h, l) WITHOUT a power-of-two scale: h = fp16(x),
+//     l = fp16(x - h) is exact to 2^-25 absolutely (fp16 subnormals), i.e. to fp32's own epsilon relative to the bound --
+//     two multiplications per pair less.
+// sine: fma, fract, sin + 2 for the split = 5 vector instructions per element (12 before).
+template <int ACT>
+WIRE_DEVINL float fx_act(float r) {
+  if (ACT == ACT_SIREN) return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(r));
+  if (ACT == ACT_GAUSS) return __builtin_amdgcn_exp2f(-(r * r));
+  return r > 0.f ? r : 0.f;
+}
+// Gabor exp(j w u - w v - s^2 (u^2 + v^2)) from (u', v') = c (u, v), c = w / 2 pi:  k1 = 2 pi log2 e, k2 = s^2 log2 e / c^2
+WIRE_DEVINL void fx_gabor(float up, float vp, float k2, float& o_re, float& o_im) {
+  const float q = __builtin_fmaf(up, up, vp * vp);
+  const float t = __builtin_fmaf(-k2, q, -9.06472028f * vp);
+  const float e = __builtin_amdgcn_exp2f(t);
+  const float fr = __builtin_amdgcn_fractf(up);
+  o_re = e * __builtin_amdgcn_cosf(fr);
+  o_im = e * __builtin_amdgcn_sinf(fr);
+}
+// (x0, x1) = H + L in packed fp16 pairs, no scale: 4 vector instructions
+WIRE_DEVINL void fx_split2(float x0, float x1, unsigned& H, unsigned& L) {
+  H = x2_cvt_pk(x0, x1);
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x0), "v"(H));
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x1), "v"(H));
+  L = x2_cvt_pk(r0, r1);
+}
+// the split of a pair: unscaled for the bounded activations, with the wave's scale for relu
+template <int KIND>
+WIRE_DEVINL void fx_split_pair(float x0, float x1, float a_scale, unsigned& H, unsigned& L) {
+  if constexpr (KIND == NK_RELU) x2_split2(x0, x1, a_scale, H, L);
+  else fx_split2(x0, x1, H, L);
 }
 
 // ---------------------------------------------------------------------------
@@ -54,15 +106,21 @@ WIRE_DEVINL void fx_dma16(const void* gsrc, unsigned char* lds_piece) {
 // with the k indices of a stage permuted as the header describes: slot (ks, e) holds k = 32 kt + 4 ks + e (e < 4) or
 // 32 kt + 16 + 4 ks + (e - 4).  Scaled by the layer's power-of-two scale (its maximum slots), split into (h, l).
 // ---------------------------------------------------------------------------
-__global__ void fx_split_b_kernel(FxSplitBatch sb, int ldb, int P) {
+// power-of-two scale of a weight image whose entries are c W: from max |W| (the layer's slots) times c -- evaluated the
+// same way where the image is written and where the kernel undoes it
+WIRE_DEVINL void fx_weight_scales(const unsigned* slots, int lane, float c, float& s, float& inv) {
+  const float m = __uint_as_float(wire_amax_read(slots, lane)) * c;
+  wire_x2_scales(__float_as_uint(m), s, inv);
+}
+__global__ void fx_split_b_kernel(FxSplitBatch sb, int ldb, int P, float c) {
   const float* __restrict__ Bt = sb.src[blockIdx.z];
   unsigned short* __restrict__ Fx = (unsigned short*)sb.dst[blockIdx.z];
   float s, inv;
-  wire_x2_scales(wire_amax_read(sb.slots[blockIdx.z], threadIdx.x & 63), s, inv);
+  fx_weight_scales(sb.slots[blockIdx.z], threadIdx.x & 63, c, s, inv);
   const int k2 = (blockIdx.x * blockDim.x + threadIdx.x) * 2;   // pair of reduction indices (same group of four)
   const int j = blockIdx.y;                                     // output column
   if (k2 >= P) return;
-  const float x0 = Bt[(size_t)j * ldb + k2], x1 = Bt[(size_t)j * ldb + k2 + 1];
+  const float x0 = c * Bt[(size_t)j * ldb + k2], x1 = c * Bt[(size_t)j * ldb + k2 + 1];
   unsigned H, L;
   x2_split2(x0, x1, s, H, L);
   const int NB = P >> 4;
@@ -74,10 +132,10 @@ __global__ void fx_split_b_kernel(FxSplitBatch sb, int ldb, int P) {
   *reinterpret_cast<unsigned*>(Fx + base + (size_t)NB * 512) = L;
 }
 int64_t fused_b_image_floats(int P) { return (int64_t)P * P; }   // 2 planes of fp16 = 4 bytes per weight
-hipError_t launch_fx_split_b_batch(hipStream_t s, const FxSplitBatch& sb, int nb, int ldb, int P) {
-  if ((P & 31) || nb < 1 || nb > FX_SPLIT_MAXB) return hipErrorInvalidValue;
+hipError_t launch_fx_split_b_batch(hipStream_t s, const FxSplitBatch& sb, int nb, int ldb, int P, float c) {
+  if ((P & 31) || nb < 1 || nb > FX_SPLIT_MAXB || !(c > 0.f)) return hipErrorInvalidValue;
   dim3 grid((unsigned)((P / 2 + 127) / 128), (unsigned)P, (unsigned)nb);
-  hipLaunchKernelGGL(fx_split_b_kernel, grid, dim3(128), 0, s, sb, ldb, P);
+  hipLaunchKernelGGL(fx_split_b_kernel, grid, dim3(128), 0, s, sb, ldb, P, c);
   return hipGetLastError();
 }
 
@@ -116,117 +174,172 @@ WIRE_DEVINL void fx_issue(const FusedFwdParams& fp, const FxCtx& c, int t, int b
 
 // top of a stage: this wave's pieces of stage c.t have landed, then everybody's (barrier); the buffer that the barrier
 // proves free (every wave has consumed stage c.t - 1) is refilled with stage c.t + RING - 1
-template <int NB, int RING>
+// (ABL: timing probes of the harness build -- results wrong -- bit 0 no producer, 1 no fragment reads, 2 no weight stream
+//  after the prologue, 3 no barrier; 0 in the product)
+template <int NB, int RING, int ABL>
 WIRE_DEVINL void fx_stage_top(const FusedFwdParams& fp, FxCtx& c) {
   constexpr int PIECES = NB / 4;
-  if (RING == 3 && c.t + 1 < c.T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  if constexpr (!(ABL & 4)) {
+    if (RING == 3 && c.t + 1 < c.T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
   if (c.t + RING - 1 < c.T) {
     int nb = c.buf + RING - 1;
     nb = nb >= RING ? nb - RING : nb;
-    fx_issue<NB, RING>(fp, c, c.t + RING - 1, nb);
+    // (the probe keeps the branch: it is what ends the scheduling region of a stage)
+    if constexpr (ABL & 4) asm volatile("s_nop 0");
+    else fx_issue<NB, RING>(fp, c, c.t + RING - 1, nb);
   }
 }
 
-// one unit of the producer: the fragments (h, l) of U / 2 stages from the coordinates (layer 0) or from the previous layer's
-// accumulators.  LAST = the values feed the final linear layer instead: no split, returned as fp32 in `of`.
-template <int KIND, int NB, bool FROM_COORDS, bool LAST>
-WIRE_DEVINL void fx_produce(const FusedFwdParams& fp, const FxCtx& c, const f32x4 (&src)[NB], const int u, const int l_src,
-                            const float a_scale, fx_f16x8 (&ah)[FxKind<KIND>::U / 2], fx_f16x8 (&al)[FxKind<KIND>::U / 2],
-                            f32x4 (&of)[FxKind<KIND>::U]) {
+// ---- the producer: one PART = the bias + activation (+ fp16 split) of 4 consecutive columns of this lane's row
+//   real nets: part cb = block cb (4 values); stage j consumes parts 2 j and 2 j + 1 as the two halves of its fragment
+//   wire:      part q = (G = q >> 1, b = q & 1): the 4 complex features 32 G + 16 b + 4 g + (0..3), i.e. blocks 4 G + b (re) and
+//              4 G + 2 + b (im); stage 2 G consumes the re halves of parts 2 G, 2 G + 1, stage 2 G + 1 their im halves
+// from the coordinates (layer 0: first_fwd_kernel's arithmetic for u, then the lean activation forms) or from the previous
+// layer's accumulators.  Pad features (>= K) are NOT zeroed here: their pre-activation is exactly 0 (zero weights and
+// bias), their activation finite, and every weight that multiplies them -- next layer's image, final image -- is 0.
+template <int KIND, int NB, bool FROM_COORDS>
+WIRE_DEVINL void fx_part(const FusedFwdParams& fp, const FxCtx& c, const f32x4 (&src)[NB], const int q, const int l_src,
+                         f32x4& o_re, f32x4& o_im) {
   constexpr bool CPLX = FxKind<KIND>::CPLX;
   constexpr int P = 16 * NB, PF = CPLX ? P / 2 : P;
   if constexpr (CPLX) {
-    // group G = u: blocks 4 G + b (re) and 4 G + 2 + b (im) of features 32 G + 16 b + 4 g + q
-    unsigned Hr[4], Lr[4], Hi[4], Li[4];
-    const float w0 = fp.w, w0l2e = fp.w * 1.44269502f, ns2l2e = -(fp.s * fp.s) * 1.44269502f;
+    const int G = q >> 1, b = q & 1;
+    f32x4 uu, vv;
+    if constexpr (FROM_COORDS) {
+      const int f0 = 32 * G + 16 * b + 4 * c.g;
+      uu = *reinterpret_cast<const f32x4*>(c.sb0 + f0);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int f0 = 32 * u + 16 * b + 4 * c.g;
-      f32x4 o_re, o_im;
-      if constexpr (FROM_COORDS) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(c.sb0 + f0);
-        f32x4 wd[4];
+      for (int d = 0; d < 4; ++d) {
+        const f32x4 wd = *reinterpret_cast<const f32x4*>(c.sW0 + d * PF + f0);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) wd[d] = *reinterpret_cast<const f32x4*>(c.sW0 + d * PF + f0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float uu = bb[q];
-#pragma unroll
-          for (int d = 0; d < 4; ++d) uu = __builtin_fmaf(c.x[d], wd[d][q], uu);
-          float a, bq;
-          gabor_fwd_real(uu, fp.w1, fp.s, a, bq);
-          const bool valid = f0 + q < fp.K;
-          o_re[q] = valid ? a : 0.f;
-          o_im[q] = valid ? bq : 0.f;
-        }
-      } else {
-        const float* bl = c.sbias + (l_src - 1) * P + 64 * u + 16 * b + 4 * c.g;
-        const f32x4 b_re = *reinterpret_cast<const f32x4*>(bl), b_im = *reinterpret_cast<const f32x4*>(bl + 32);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float uu = src[4 * u + b][q] * c.inv_prev + b_re[q];
-          const float vv = src[4 * u + 2 + b][q] * c.inv_prev + b_im[q];
-          float a, bq;
-          gabor_fwd_lean(uu, vv, w0, w0l2e, ns2l2e, a, bq);
-          const bool valid = f0 + q < fp.K;
-          o_re[q] = valid ? a : 0.f;
-          o_im[q] = valid ? bq : 0.f;
-        }
+        for (int e = 0; e < 4; ++e) uu[e] = __builtin_fmaf(c.x[d], wd[e], uu[e]);
       }
-      if constexpr (LAST) { of[b] = o_re; of[2 + b] = o_im; }
-      else {
-        x2_split2(o_re[0], o_re[1], a_scale, Hr[2 * b], Lr[2 * b]);
-        x2_split2(o_re[2], o_re[3], a_scale, Hr[2 * b + 1], Lr[2 * b + 1]);
-        x2_split2(o_im[0], o_im[1], a_scale, Hi[2 * b], Li[2 * b]);
-        x2_split2(o_im[2], o_im[3], a_scale, Hi[2 * b + 1], Li[2 * b + 1]);
+      vv = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      const float* bl = c.sbias + (l_src - 1) * P + 64 * G + 16 * b + 4 * c.g;
+      const f32x4 b_re = *reinterpret_cast<const f32x4*>(bl), b_im = *reinterpret_cast<const f32x4*>(bl + 32);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        uu[e] = __builtin_fmaf(src[4 * G + b][e], c.inv_prev, b_re[e]);
+        vv[e] = __builtin_fmaf(src[4 * G + 2 + b][e], c.inv_prev, b_im[e]);
       }
     }
-    if constexpr (!LAST) {
-      ah[0] = __builtin_bit_cast(fx_f16x8, fx_u32x4{Hr[0], Hr[1], Hr[2], Hr[3]});
-      al[0] = __builtin_bit_cast(fx_f16x8, fx_u32x4{Lr[0], Lr[1], Lr[2], Lr[3]});
-      ah[1] = __builtin_bit_cast(fx_f16x8, fx_u32x4{Hi[0], Hi[1], Hi[2], Hi[3]});
-      al[1] = __builtin_bit_cast(fx_f16x8, fx_u32x4{Li[0], Li[1], Li[2], Li[3]});
+    const float k2 = FROM_COORDS ? fp.k2_first : fp.k2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a, bq;
+      fx_gabor(uu[e], vv[e], k2, a, bq);
+      o_re[e] = a; o_im[e] = bq;
     }
   } else {
     constexpr int ACT = FxKind<KIND>::ACT;
-    unsigned H[4], Lo[4];
+    const int col = 16 * q + 4 * c.g;
+    f32x4 lin;
+    if constexpr (FROM_COORDS) {
+      lin = *reinterpret_cast<const f32x4*>(c.sb0 + col);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int col = 16 * (2 * u + b) + 4 * c.g;
-      f32x4 o;
+      for (int d = 0; d < 4; ++d) {
+        const f32x4 wd = *reinterpret_cast<const f32x4*>(c.sW0 + d * PF + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lin[e] = __builtin_fmaf(c.x[d], wd[e], lin[e]);
+      }
+    } else {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(c.sbias + (l_src - 1) * P + col);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lin[e] = __builtin_fmaf(src[q][e], c.inv_prev, bv[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o_re[e] = fx_act<ACT>(lin[e]);
+    o_im = o_re;
+  }
+}
+
+template <int KIND, int NB> constexpr int fx_nparts() { return FxKind<KIND>::CPLX ? NB / 2 : NB; }
+
+// ---- the producer in SLICES.  The production of one part is cut into steps -- pre-activation (LDS reads of the bias row),
+// one activation per element, the fp16 splits -- and step k of the part(s) a stage produces runs behind the MFMAs of
+// column block cb = k * stride of that stage, so that every block of the stage carries three MFMAs, two weight-fragment
+// reads (of the next block) and a few vector instructions: the schedule is in the source, block by block.
+//   real nets: two parts per stage (q = 2 + 2 j + i, i = cb / (NB / 2)), 7 steps each: lin | act 0..3 | split 01 | split 23
+//   wire:      one part per stage (q = 2 + j), 9 steps: lin | gabor 0..3 | split re01 | re23 | im01 | im23
+// `w` holds the part in flight: real [lin, out]; wire [u, v, o_re, o_im].
+template <int KIND, int NB, bool FROM_COORDS>
+WIRE_DEVINL void fx_slice(const FusedFwdParams& fp, const FxCtx& c, const f32x4 (&src)[NB], const int l_src,
+                          const float a_scale, const int j, const int cb, f32x4 (&w)[4], fx_u32x4 (&Fh)[NB / 2],
+                          fx_u32x4 (&Fl)[NB / 2]) {
+  constexpr bool CPLX = FxKind<KIND>::CPLX;
+  constexpr int P = 16 * NB, PF = CPLX ? P / 2 : P, NP = fx_nparts<KIND, NB>();
+  if constexpr (CPLX) {
+    constexpr int ST = NB / 9;                            // block stride between steps
+    const int q = 2 + j;
+    if (q >= NP || cb % ST != 0 || cb / ST > 8) return;
+    const int k = cb / ST, G = q >> 1, b = q & 1;
+    if (k == 0) {
       if constexpr (FROM_COORDS) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(c.sb0 + col);
-        f32x4 wd[4];
+        const int f0 = 32 * G + 16 * b + 4 * c.g;
+        f32x4 uu = *reinterpret_cast<const f32x4*>(c.sb0 + f0);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) wd[d] = *reinterpret_cast<const f32x4*>(c.sW0 + d * PF + col);
+        for (int d = 0; d < 4; ++d) {
+          const f32x4 wd = *reinterpret_cast<const f32x4*>(c.sW0 + d * PF + f0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float uu = bb[q];
-#pragma unroll
-          for (int d = 0; d < 4; ++d) uu = __builtin_fmaf(c.x[d], wd[d][q], uu);
-          const float v = real_act_fwd<ACT>(uu, fp.w1, fp.s);
-          o[q] = col + q < fp.K ? v : 0.f;
+          for (int e = 0; e < 4; ++e) uu[e] = __builtin_fmaf(c.x[d], wd[e], uu[e]);
         }
+        w[0] = uu; w[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        const float* bl = c.sbias + (l_src - 1) * P + 64 * G + 16 * b + 4 * c.g;
+        const f32x4 b_re = *reinterpret_cast<const f32x4*>(bl), b_im = *reinterpret_cast<const f32x4*>(bl + 32);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          w[0][e] = __builtin_fmaf(src[4 * G + b][e], c.inv_prev, b_re[e]);
+          w[1][e] = __builtin_fmaf(src[4 * G + 2 + b][e], c.inv_prev, b_im[e]);
+        }
+      }
+    } else if (k <= 4) {
+      const int e = k - 1;
+      float a, bq;
+      fx_gabor(w[0][e], w[1][e], FROM_COORDS ? fp.k2_first : fp.k2, a, bq);
+      w[2][e] = a; w[3][e] = bq;
+    } else {
+      const int im = (k - 5) >> 1, pr = (k - 5) & 1;      // re / im plane, element pair
+      unsigned h, lo;
+      fx_split_pair<KIND>(w[2 + im][2 * pr], w[2 + im][2 * pr + 1], a_scale, h, lo);
+      Fh[2 * G + im][2 * b + pr] = h;
+      Fl[2 * G + im][2 * b + pr] = lo;
+    }
+  } else {
+    constexpr int ACT = FxKind<KIND>::ACT;
+    constexpr int HB = NB / 2;                            // blocks per part
+    static_assert(CPLX || HB >= 7, "seven producer steps per part");
+    const int i = cb / HB, k = cb % HB;
+    const int q = 2 + 2 * j + i;
+    if (q >= NP || k > 6) return;
+    if (k == 0) {
+      const int col = 16 * q + 4 * c.g;
+      if constexpr (FROM_COORDS) {
+        f32x4 lin = *reinterpret_cast<const f32x4*>(c.sb0 + col);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const f32x4 wd = *reinterpret_cast<const f32x4*>(c.sW0 + d * PF + col);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lin[e] = __builtin_fmaf(c.x[d], wd[e], lin[e]);
+        }
+        w[0] = lin;
       } else {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(c.sbias + (l_src - 1) * P + col);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float lin = src[2 * u + b][q] * c.inv_prev + bv[q];
-          const float v = real_act_fwd_lean<ACT>(lin, fp.w, fp.s);
-          o[q] = col + q < fp.K ? v : 0.f;
-        }
+        for (int e = 0; e < 4; ++e) w[0][e] = __builtin_fmaf(src[q][e], c.inv_prev, bv[e]);
       }
-      if constexpr (LAST) of[b] = o;
-      else {
-        x2_split2(o[0], o[1], a_scale, H[2 * b], Lo[2 * b]);
-        x2_split2(o[2], o[3], a_scale, H[2 * b + 1], Lo[2 * b + 1]);
-      }
-    }
-    if constexpr (!LAST) {
-      ah[0] = __builtin_bit_cast(fx_f16x8, fx_u32x4{H[0], H[1], H[2], H[3]});
-      al[0] = __builtin_bit_cast(fx_f16x8, fx_u32x4{Lo[0], Lo[1], Lo[2], Lo[3]});
+    } else if (k <= 4) {
+      w[1][k - 1] = fx_act<ACT>(w[0][k - 1]);
+    } else {
+      const int pr = k - 5;
+      unsigned h, lo;
+      fx_split_pair<KIND>(w[1][2 * pr], w[1][2 * pr + 1], a_scale, h, lo);
+      Fh[q >> 1][2 * (q & 1) + pr] = h;
+      Fl[q >> 1][2 * (q & 1) + pr] = lo;
     }
   }
 }
@@ -236,17 +349,13 @@ WIRE_DEVINL void fx_produce(const FusedFwdParams& fp, const FxCtx& c, const f32x
 template <int KIND, int NB, bool FROM_COORDS>
 WIRE_DEVINL float fx_wave_scale(const FusedFwdParams& fp, const FxCtx& c, const f32x4 (&src)[NB], const int l_src,
                                 float& inv) {
-  constexpr int U = FxKind<KIND>::U, NU = NB / U;
   float m = 0.f;
 #pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    fx_f16x8 dh[U / 2], dl[U / 2];
-    f32x4 of[U];
-    fx_produce<KIND, NB, FROM_COORDS, true>(fp, c, src, u, l_src, 1.f, dh, dl, of);
+  for (int q = 0; q < fx_nparts<KIND, NB>(); ++q) {
+    f32x4 o_re, o_im;
+    fx_part<KIND, NB, FROM_COORDS>(fp, c, src, q, l_src, o_re, o_im);
 #pragma unroll
-    for (int b = 0; b < U; ++b)
-      m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(of[b][0]), __builtin_fabsf(of[b][1])),
-                                             __builtin_fmaxf(__builtin_fabsf(of[b][2]), __builtin_fabsf(of[b][3]))));
+    for (int e = 0; e < 4; ++e) m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(o_re[e]), __builtin_fabsf(o_im[e])));
   }
 #pragma unroll
   for (int o = 32; o; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o));
@@ -256,42 +365,54 @@ WIRE_DEVINL float fx_wave_scale(const FusedFwdParams& fp, const FxCtx& c, const 
 }
 
 // hidden layer l (1 .. L):  dst = h_{l-1} W_l^T  with the operands' scales still on it; h_{l-1} comes from the coordinates
-// (l = 1) or from `src`, the accumulators of layer l - 1
-template <int KIND, int NB, int RING, bool FROM_COORDS>
+// (l = 1) or from `src`, the accumulators of layer l - 1.  During the MFMAs of stage j the vector unit produces what stage
+// j + 1 (real nets: parts 2 j + 2, 2 j + 3) or the stage pair after the current one (wire: part j + 2) will consume.
+template <int KIND, int NB, int RING, bool FROM_COORDS, int ABL>
 WIRE_DEVINL void fx_layer(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)[NB], f32x4 (&dst)[NB], const int l) {
-  constexpr int U = FxKind<KIND>::U, NU = NB / U, HS = U / 2, STAGE = NB * 2048;
-  float sA = fp.a_scale, invA = fp.a_scale_inv;
+  constexpr bool CPLX = FxKind<KIND>::CPLX;
+  constexpr int S = NB / 2, STAGE = NB * 2048;
+  float sA = 1.f, invA = 1.f;                          // (bounded activations are split unscaled)
   if constexpr (KIND == NK_RELU) sA = fx_wave_scale<KIND, NB, FROM_COORDS>(fp, c, src, l - 1, invA);
   float sB, invB;
-  wire_x2_scales(wire_amax_read(fp.wamax + (size_t)(l - 1) * fp.wamax_stride, c.lane), sB, invB);
+  fx_weight_scales(fp.wamax + (size_t)(l - 1) * fp.wamax_stride, c.lane, fp.c_hidden, sB, invB);
   (void)sB;
+  fx_u32x4 Fh[S], Fl[S];
+  f32x4 w[4];
+  // parts 0 and 1 (what stage 0 -- wire: stages 0 and 1 -- consumes) before the first stage
 #pragma unroll
-  for (int cb = 0; cb < NB; ++cb) dst[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  fx_f16x8 ah[HS], al[HS], nh[HS], nl[HS];
-  f32x4 unused[U];
-  fx_produce<KIND, NB, FROM_COORDS, false>(fp, c, src, 0, l - 1, sA, ah, al, unused);
+  for (int jj = (CPLX ? -2 : -1); jj < 0; ++jj)
 #pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    // the NEXT unit's fragments: vector work that runs under this unit's MFMAs
-    if (u + 1 < NU) fx_produce<KIND, NB, FROM_COORDS, false>(fp, c, src, u + 1, l - 1, sA, nh, nl, unused);
+    for (int cb = 0; cb < NB; ++cb) fx_slice<KIND, NB, FROM_COORDS>(fp, c, src, l - 1, sA, jj, cb, w, Fh, Fl);
 #pragma unroll
-    for (int sub = 0; sub < HS; ++sub) {
-      fx_stage_top<NB, RING>(fp, c);
-      const unsigned char* Sb = c.ring + c.buf * STAGE + c.lane * 16;
+  for (int j = 0; j < S; ++j) {
+    fx_stage_top<NB, RING, ABL>(fp, c);
+    const unsigned char* Sb = c.ring + c.buf * STAGE + c.lane * 16;
+    const fx_f16x8 ah = __builtin_bit_cast(fx_f16x8, Fh[j]), al = __builtin_bit_cast(fx_f16x8, Fl[j]);
+    // weight fragments FX_PFD blocks ahead, in a rotating set of registers
+    fx_f16x8 bh[FX_PFD + 1], bl[FX_PFD + 1];
 #pragma unroll
-      for (int cb = 0; cb < NB; ++cb) {
-        const fx_f16x8 bh = *reinterpret_cast<const fx_f16x8*>(Sb + cb * 1024);
-        const fx_f16x8 bl = *reinterpret_cast<const fx_f16x8*>(Sb + (NB + cb) * 1024);
-        // small terms first; weights as the first operand: the block comes out transposed (row = lane & 15)
-        FX_MFMA(bl, ah[sub], dst[cb]);
-        FX_MFMA(bh, al[sub], dst[cb]);
-        FX_MFMA(bh, ah[sub], dst[cb]);
-      }
-      c.t += 1;
-      c.buf = c.buf + 1 == RING ? 0 : c.buf + 1;
+    for (int cb = 0; cb < FX_PFD; ++cb) {
+      bh[cb] = *reinterpret_cast<const fx_f16x8*>(Sb + cb * 1024);
+      bl[cb] = *reinterpret_cast<const fx_f16x8*>(Sb + (NB + cb) * 1024);
     }
 #pragma unroll
-    for (int sub = 0; sub < HS; ++sub) { ah[sub] = nh[sub]; al[sub] = nl[sub]; }
+    for (int cb = 0; cb < NB; ++cb) {
+      if (cb + FX_PFD < NB && !(ABL & 2)) {
+        bh[(cb + FX_PFD) % (FX_PFD + 1)] = *reinterpret_cast<const fx_f16x8*>(Sb + (cb + FX_PFD) * 1024);
+        bl[(cb + FX_PFD) % (FX_PFD + 1)] = *reinterpret_cast<const fx_f16x8*>(Sb + (NB + cb + FX_PFD) * 1024);
+      }
+      fx_f16x8 xh = bh[(ABL & 2) ? 0 : cb % (FX_PFD + 1)], xl = bl[(ABL & 2) ? 0 : cb % (FX_PFD + 1)];
+      if constexpr (ABL & 2) { asm volatile("" : "+v"(xh)); asm volatile("" : "+v"(xl)); }   // (probe: no reads, no CSE)
+      // small terms first; weights as the first operand: the block comes out transposed (row = lane & 15)
+      if (j == 0) dst[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, ah, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      else FX_MFMA(xl, ah, dst[cb]);
+      FX_MFMA(xh, al, dst[cb]);
+      FX_MFMA(xh, ah, dst[cb]);
+      if constexpr (!(ABL & 1)) fx_slice<KIND, NB, FROM_COORDS>(fp, c, src, l - 1, sA, j, cb, w, Fh, Fl);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    c.t += 1;
+    c.buf = c.buf + 1 == RING ? 0 : c.buf + 1;
   }
   c.inv_prev = invA * invB;
 }
@@ -301,22 +422,23 @@ WIRE_DEVINL void fx_layer(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)
 template <int KIND, int NB>
 WIRE_DEVINL void fx_final(const FusedFwdParams& fp, const FxCtx& c, const f32x4 (&src)[NB]) {
   constexpr bool CPLX = FxKind<KIND>::CPLX;
-  constexpr int U = FxKind<KIND>::U, NU = NB / U, P = 16 * NB;
+  constexpr int P = 16 * NB;
   float yo[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    fx_f16x8 dh[U / 2], dl[U / 2];
-    f32x4 of[U];
-    fx_produce<KIND, NB, false, true>(fp, c, src, u, fp.L, 1.f, dh, dl, of);
+  for (int q = 0; q < fx_nparts<KIND, NB>(); ++q) {
+    f32x4 o_re, o_im;
+    fx_part<KIND, NB, false>(fp, c, src, q, fp.L, o_re, o_im);
+    const int col = CPLX ? 64 * (q >> 1) + 16 * (q & 1) + 4 * c.g : 16 * q + 4 * c.g;
 #pragma unroll
-    for (int b = 0; b < U; ++b) {
-      const int col = CPLX ? 64 * u + 32 * (b >> 1) + 16 * (b & 1) + 4 * c.g : 16 * (2 * u + b) + 4 * c.g;
+    for (int o = 0; o < 4; ++o) {
+      if (o < fp.O) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(c.swf + o * P + col);
 #pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        if (o < fp.O) {
-          const f32x4 wv = *reinterpret_cast<const f32x4*>(c.swf + o * P + col);
+        for (int e = 0; e < 4; ++e) yo[o] = __builtin_fmaf(o_re[e], wv[e], yo[o]);
+        if constexpr (CPLX) {
+          const f32x4 wi = *reinterpret_cast<const f32x4*>(c.swf + o * P + col + 32);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) yo[o] = __builtin_fmaf(of[b][q], wv[q], yo[o]);
+          for (int e = 0; e < 4; ++e) yo[o] = __builtin_fmaf(o_im[e], wi[e], yo[o]);
         }
       }
     }
@@ -338,7 +460,7 @@ constexpr int fx_lds_bytes() {
   return RING * NB * 2048 + (4 * 16 * NB + 16 * NB + FX_LMAX * 16 * NB + 4 * 16 * NB) * 4;   // (first layer sized for PF = P)
 }
 
-template <int KIND, int NB, int RING>
+template <int KIND, int NB, int RING, int ABL = 0>
 __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwdParams fp) {
   constexpr bool CPLX = FxKind<KIND>::CPLX;
   constexpr int P = 16 * NB, PF = CPLX ? P / 2 : P, S = NB / 2, STAGE = NB * 2048;
@@ -369,12 +491,12 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwd
   }
   for (int i = tid; i < 4 * PF; i += 64 * FX_WAVES) {
     const int d = i / PF, f = i - d * PF;
-    sW0[i] = (d < fp.D && f < fp.K) ? fp.W0[f * fp.D + d] : 0.f;
+    sW0[i] = (d < fp.D && f < fp.K) ? fp.c_first * fp.W0[f * fp.D + d] : 0.f;
   }
-  for (int i = tid; i < PF; i += 64 * FX_WAVES) sb0[i] = i < fp.K ? fp.b0[i] : 0.f;
+  for (int i = tid; i < PF; i += 64 * FX_WAVES) sb0[i] = i < fp.K ? fp.c_first * fp.b0[i] : 0.f;
   for (int i = tid; i < fp.L * P; i += 64 * FX_WAVES) {
     const int l = i / P;
-    sbias[i] = fp.bias[(size_t)l * fp.bias_stride + (i - l * P)];
+    sbias[i] = fp.c_hidden * fp.bias[(size_t)l * fp.bias_stride + (i - l * P)];
   }
   for (int i = tid; i < fp.O * P; i += 64 * FX_WAVES) swf[i] = fp.wf[i];
   __syncthreads();
@@ -382,14 +504,14 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwd
   f32x4 accA[NB], accB[NB];
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb) accB[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  fx_layer<KIND, NB, RING, true>(fp, c, accB, accA, 1);
+  fx_layer<KIND, NB, RING, true, ABL>(fp, c, accB, accA, 1);
   int l = 2;
   for (; l + 1 <= fp.L; l += 2) {
-    fx_layer<KIND, NB, RING, false>(fp, c, accA, accB, l);
-    fx_layer<KIND, NB, RING, false>(fp, c, accB, accA, l + 1);
+    fx_layer<KIND, NB, RING, false, ABL>(fp, c, accA, accB, l);
+    fx_layer<KIND, NB, RING, false, ABL>(fp, c, accB, accA, l + 1);
   }
   if (l <= fp.L) {
-    fx_layer<KIND, NB, RING, false>(fp, c, accA, accB, l);
+    fx_layer<KIND, NB, RING, false, ABL>(fp, c, accA, accB, l);
     fx_final<KIND, NB>(fp, c, accB);
   } else {
     fx_final<KIND, NB>(fp, c, accA);
@@ -405,12 +527,18 @@ static int fx_env(const char* name, int dflt) {
 }
 // "fused_fwd" / WIRE_FUSED_FWD: 1 (default) = forward-only calls of the nets below run the fused kernel
 static std::atomic<int> g_fused_fwd{fx_env("WIRE_FUSED_FWD", 1)};
+#ifdef WIRE_FX_ABLATE
+static std::atomic<int> g_fx_ablate{0};
+#endif
 int fused_tune_get(const char* key) {
   if (!strcmp(key, "fused_fwd")) return g_fused_fwd;
   return -1;
 }
 int fused_tune_set(const char* key, int value) {
   if (!strcmp(key, "fused_fwd") && value >= 0 && value <= 1) { g_fused_fwd = value; return 0; }
+#ifdef WIRE_FX_ABLATE
+  if (!strcmp(key, "fx_ablate") && value >= 0 && value <= 15) { g_fx_ablate = value; return 0; }
+#endif
   return -1;
 }
 
@@ -422,16 +550,21 @@ bool fused_fwd_shape(int kind, int P) {
   return false;
 }
 bool fused_fwd_enabled() { return g_fused_fwd != 0; }
+float fused_pre_scale(int kind, float omega0, float scale0) {
+  if (kind == NK_SIREN || kind == NK_WIRE) return (float)((double)omega0 / 6.283185307179586);
+  if (kind == NK_GAUSS) return (float)((double)scale0 * 1.2011224087864498);      // sqrt(log2 e)
+  return 1.f;
+}
 
-template <int KIND, int NB, int RING>
+template <int KIND, int NB, int RING, int ABL = 0>
 static hipError_t fx_launch_t(hipStream_t s, const FusedFwdParams& fp) {
   constexpr int LDS = fx_lds_bytes<NB, RING>();
   static_assert(LDS <= 160 * 1024, "LDS budget of a CU");
-  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_kernel<KIND, NB, RING>),
+  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_kernel<KIND, NB, RING, ABL>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (attr != hipSuccess) return attr;
   const unsigned grid = (unsigned)((fp.n + FX_ROWS - 1) / FX_ROWS);
-  hipLaunchKernelGGL((fused_fwd_kernel<KIND, NB, RING>), dim3(grid), dim3(64 * FX_WAVES), LDS, s, fp);
+  hipLaunchKernelGGL((fused_fwd_kernel<KIND, NB, RING, ABL>), dim3(grid), dim3(64 * FX_WAVES), LDS, s, fp);
   return hipGetLastError();
 }
 
@@ -440,7 +573,21 @@ hipError_t launch_fused_fwd(hipStream_t s, int kind, int P, const FusedFwdParams
   if (!fused_fwd_shape(kind, P) || fp.L < 1 || fp.L > FX_LMAX || fp.D < 1 || fp.D > 4 || fp.O < 1 || fp.O > 4 ||
       fp.n > 0x7fffffffLL * FX_ROWS)
     return hipErrorInvalidValue;
-  if (kind != NK_RELU && !(fp.a_scale > 0.f)) return hipErrorInvalidValue;
+  if (!(fp.c_first > 0.f) || !(fp.c_hidden > 0.f)) return hipErrorInvalidValue;
+#ifdef WIRE_FX_ABLATE
+  if (kind == NK_SIREN) {
+    switch (g_fx_ablate.load()) {
+      case 1: return fx_launch_t<NK_SIREN, 16, 3, 1>(s, fp);
+      case 2: return fx_launch_t<NK_SIREN, 16, 3, 2>(s, fp);
+      case 3: return fx_launch_t<NK_SIREN, 16, 3, 3>(s, fp);
+      case 4: return fx_launch_t<NK_SIREN, 16, 3, 4>(s, fp);
+      case 8: return fx_launch_t<NK_SIREN, 16, 3, 8>(s, fp);
+      case 12: return fx_launch_t<NK_SIREN, 16, 3, 12>(s, fp);
+      case 15: return fx_launch_t<NK_SIREN, 16, 3, 15>(s, fp);
+      default: break;
+    }
+  }
+#endif
   switch (kind) {
     case NK_SIREN: return fx_launch_t<NK_SIREN, 16, 3>(s, fp);
     case NK_GAUSS: return fx_launch_t<NK_GAUSS, 16, 3>(s, fp);
@@ -452,3 +599,7 @@ hipError_t launch_fused_fwd(hipStream_t s, int kind, int P, const FusedFwdParams
     default: return hipErrorInvalidValue;
   }
 }
+
+#ifdef FX_PROBE_ABL
+template __global__ void fused_fwd_kernel<NK_SIREN, 16, 3, FX_PROBE_ABL>(const FusedFwdParams);
+#endif

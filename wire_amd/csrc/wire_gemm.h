@@ -139,7 +139,8 @@ hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float*
 #define FX_SPLIT_MAXB 32
 struct FxSplitBatch { const float* src[FX_SPLIT_MAXB]; void* dst[FX_SPLIT_MAXB]; const unsigned* slots[FX_SPLIT_MAXB]; };
 int64_t fused_b_image_floats(int P);                      // floats of one hidden layer's image
-hipError_t launch_fx_split_b_batch(hipStream_t s, const FxSplitBatch& sb, int nb, int ldb, int P);
+// c: the constant folded into the weights (fused_pre_scale of the net kind and its omega_0 / scale_0)
+hipError_t launch_fx_split_b_batch(hipStream_t s, const FxSplitBatch& sb, int nb, int ldb, int P, float c);
 struct FusedFwdParams {
   const float* coords = nullptr; long long n = 0;         // [n][D]
   const float* W0 = nullptr; const float* b0 = nullptr;   // first layer, native [K][D], [K]
@@ -150,8 +151,12 @@ struct FusedFwdParams {
   float* y = nullptr;                                     // [n][O]
   int D = 0, K = 0, L = 0, O = 0;
   float w1 = 0.f, w = 0.f, s = 0.f;                       // first omega_0, hidden omega_0, scale_0
-  float a_scale = 0.f, a_scale_inv = 0.f;                 // power-of-two scale of the activations (relu: the wave's own maximum)
+  // constants folded into the pre-activations: r = c lin with c = omega_0 / 2 pi (sine, Gabor), scale_0 sqrt(log2 e)
+  // (Gaussian), 1 (relu) -- c_first for layer 0 (first omega_0; applied to W0, b0 on the fly), c_hidden in the hidden
+  // layers' images and biases; Gabor envelope: k2 = scale_0^2 log2 e / c^2
+  float c_first = 1.f, c_hidden = 1.f, k2_first = 0.f, k2 = 0.f;
 };
+float fused_pre_scale(int kind, float omega0, float scale0);   // the c of a layer with these hyper-parameters
 bool fused_fwd_shape(int kind, int P);
 bool fused_fwd_enabled();
 int fused_tune_get(const char* key);                      // "fused_fwd"; -1 = unknown key

@@ -39,7 +39,7 @@ class _INRFunction(torch.autograd.Function):
     """Whole-network forward/backward: wire_mlp_fwd / wire_mlp_bwd."""
 
     @staticmethod
-    def forward(ctx, coords: torch.Tensor, desc: _lib.NetDesc, *params: torch.Tensor):
+    def forward(ctx, coords: torch.Tensor, desc: _lib.NetDesc, grad_mode: bool, *params: torch.Tensor):
         L = _lib.lib()
         _require_cuda(coords, "coords")
         dev = coords.device
@@ -55,7 +55,10 @@ class _INRFunction(torch.autograd.Function):
         packed = torch.empty(L.wire_packed_floats(C.byref(desc)), dtype=torch.float32, device=dev)
         _lib.check(L.wire_pack_params(stream, C.byref(desc), _lib.ptr_array([p.data_ptr() for p in nat]),
                                       packed.data_ptr()), "wire_pack_params")
-        need_bwd = any(ctx.needs_input_grad[2:])
+        # (inside torch.no_grad() needs_input_grad still reports the parameters' requires_grad; no graph is recorded
+        #  there, so nothing is saved and the forward-only kernels run.  grad_mode = torch.is_grad_enabled() at the call:
+        #  inside forward() it is always off)
+        need_bwd = grad_mode and any(ctx.needs_input_grad[3:])
         act_bytes = _lib.check(L.wire_act_bytes(C.byref(desc), n, int(need_bwd)), "wire_act_bytes")
         act = torch.empty(act_bytes, dtype=torch.uint8, device=dev)
         y = torch.empty(tuple(coords.shape[:-1]) + (O,), dtype=torch.float32, device=dev)
@@ -85,11 +88,11 @@ class _INRFunction(torch.autograd.Function):
         # the saved buffers stay with the graph node (freed with it), so backward(retain_graph=True) can run again.
         # No gradient is returned for `coords` (the reference's autograd would produce one; no caller in the
         # reference asks for it -- INTEGRATION.md)
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
 def inr_forward(coords: torch.Tensor, desc: _lib.NetDesc, params: Sequence[torch.Tensor]) -> torch.Tensor:
-    return _INRFunction.apply(coords, desc, *params)
+    return _INRFunction.apply(coords, desc, torch.is_grad_enabled(), *params)
 
 
 class _GaborLayerFunction(torch.autograd.Function):
