@@ -350,6 +350,38 @@ def extras(dev, lib):
                                         "frac_of_fp32_mfma_peak": SIDE * SIDE / dt * Ff / 1e12 / PEAK_FP32_MFMA_TFLOPS}
     del tr, model
     torch.cuda.empty_cache()
+    # forward-only of the nets that have the whole-net kernel (wire_fused.hip: activations in registers from the coordinates
+    # to the output): the reference-API width and BASELINE.json configs[4]'s real nets
+    _, _, peak = family(lib)
+    for name, kind, hf, kw in (("forward_only_k181", "wire", 256, wire_kw),
+                               ("forward_only_siren", "siren", 256, dict(first_omega_0=30.0, hidden_omega_0=30.0)),
+                               ("forward_only_gauss", "gauss", 256, dict(scale=10.0)),
+                               ("forward_only_relu", "relu", 256, {})):
+        torch.manual_seed(0)
+        model = models.get_INR(nonlin=kind, in_features=D, out_features=O, hidden_features=hf, hidden_layers=L, **kw).to(dev)
+        Kk = model._arch["width"]
+        tr = FusedTrainer(model, (SIDE, SIDE), torch.zeros(SIDE * SIDE, O), lr=5e-3)
+        best = {}
+        for knob in (1, 0):
+            lib.wire_tune_set(b"fused_fwd", knob)
+            tr.render()
+            torch.cuda.synchronize()
+            dt = float("inf")
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    tr.render()
+                torch.cuda.synchronize()
+                dt = min(dt, (time.perf_counter() - t0) / 5)
+            best[knob] = dt
+        lib.wire_tune_set(b"fused_fwd", 1)
+        Ff = (8 * Kk * Kk * L + 2 * D * Kk + 4 * Kk * O) if kind == "wire" else (2 * Kk * Kk * L + 2 * D * Kk + 2 * Kk * O)
+        res[name] = {"samples_per_s": SIDE * SIDE / best[1], "ms": best[1] * 1e3, "K": Kk,
+                     "layer_by_layer_samples_per_s": SIDE * SIDE / best[0], "layer_by_layer_ms": best[0] * 1e3,
+                     "frac": SIDE * SIDE / best[1] * Ff / 1e12 / peak, "alg_flop_per_sample": Ff,
+                     "kernel": "fused_fwd_kernel (wire_fused.hip) incl. packing and coordinate launches"}
+        del tr, model
+        torch.cuda.empty_cache()
     # the exact-fp32 family (fp32 MFMA, 3-multiplication complex GEMMs) on the headline workload: the
     # north-star's literal realisation and the fallback should the split ever be contested
     if lib.wire_tune_get(b"split_bf16") == 1:
@@ -402,6 +434,74 @@ def extras(dev, lib):
     return res
 
 
+def secondary(ex):
+    """Flat, driver-visible copy of the secondary claims: samples/s and the whole-step fraction of
+    the family's roofline (833.3 fp32-equivalent TFLOP/s for the 2 x fp16 split; SURVEY 8(d) flop counts) for the other
+    BASELINE.json configs, the reference-API width, forward-only inference and the exact-fp32 family."""
+    out = {}
+    for key, short in (("k181_api_hidden_features_256", "k181"), ("cfg4_wire2d_4x256_1024x1024", "cfg4_wire2d"),
+                       ("cfg5_siren_4x256", "cfg5_siren"), ("cfg5_gauss_4x256", "cfg5_gauss"),
+                       ("cfg5_relu_4x256", "cfg5_relu"), ("cfg5_relu_posenc_4x256", "cfg5_relu_posenc"),
+                       ("fp32_mfma_family", "fp32_mfma_family"), ("bf16x3_family", "bf16x3_family")):
+        if key in ex:
+            out[short + "_samples_per_s"] = ex[key]["samples_per_s"]
+            out[short + "_ms_per_step"] = ex[key]["ms_per_step"]
+            out[short + "_whole_step_frac"] = ex[key]["whole_step_frac"]
+            if "hbm_bound" in ex[key]:
+                out[short + "_alg_TBps"] = ex[key]["hbm_bound"]["achieved_TBps"]
+    for key in ("forward_only_k256_literal", "forward_only_k181", "forward_only_siren", "forward_only_gauss",
+                "forward_only_relu"):
+        if key in ex:
+            out[key + "_samples_per_s"] = ex[key]["samples_per_s"]
+            if "frac" in ex[key]:
+                out[key + "_frac"] = ex[key]["frac"]
+    for key in ("reference_loop_unchanged", "reference_loop_device_resident", "randperm_shuffle"):
+        if key in ex:
+            out[key + "_samples_per_s"] = ex[key]["samples_per_s"]
+    return out
+
+
+def rccl_probe(dev, tr, timeout_s=45.0):
+    """What RCCL ITSELF reports about the job: ncclCommCount / ncclCommCuDevice of a communicator
+    built from librccl's C ABI (the trainer's own when WIRE_DP_DIRECT=1, else one made here with the symmetric set-up of
+    parallel.RcclDirect) and one all-reduce of ones on it, which must come back as the world size.  Runs on every rank
+    AFTER the timed region, in a thread with a deadline: a communicator that cannot be built must not cost the run its
+    number.  Returns a dict for config.rccl_*; "timeout" marks a probe that did not finish (the caller then leaves through
+    os._exit so that a stuck rendezvous cannot hang the teardown)."""
+    import threading
+    import torch
+    import torch.distributed as dist
+    from wire_amd.parallel import RcclDirect
+    res = {}
+
+    def work():
+        try:
+            comm = tr.reducers[0].direct
+            own = comm is None
+            if own:
+                comm = RcclDirect(dev)
+            res["rccl_nranks"] = comm.comm_count()
+            res["rccl_device"] = comm.comm_device()
+            ones = torch.ones(4, device=dev, dtype=torch.float32)
+            comm.all_reduce_sum_(ones)
+            torch.cuda.synchronize(dev)
+            res["rccl_allreduce_of_ones"] = float(ones[0].item())
+            res["rccl_communicator"] = "the trainer's (WIRE_DP_DIRECT=1)" if not own else "probe only (training used torch.distributed.all_reduce)"
+            if own:
+                comm.close()
+        except Exception as e:                              # noqa: BLE001
+            res["rccl_error"] = f"{type(e).__name__}: {e}"
+
+    if dist.get_backend() != "nccl":
+        return {"rccl_nranks": None, "rccl_note": f"backend {dist.get_backend()}: no RCCL communicator in this run"}
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        return {"rccl_nranks": None, "rccl_error": "timeout", "timeout": True}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -411,11 +511,27 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--hidden-features", type=int, default=HIDDEN_FEATURES)
+    ap.add_argument("--overlap", choices=["none", "layer", "micro"], default=None,
+                    help="shape of the gradient exchange at N > 1 (VERDICT r03 item 6b): none = one all-reduce of the whole "
+                         "buffer after the backward (default), layer = per layer on a side stream under the backward "
+                         "(WIRE_DP_OVERLAP=layer), micro = two micro-shards, the first one's all-reduce under the second "
+                         "one's forward + backward (--micro-shards 2)")
+    ap.add_argument("--dp-direct", type=int, choices=[0, 1], default=None,
+                    help="1: ncclAllReduce of librccl's C ABI on the compute stream (parallel.RcclDirect); 0 (default): "
+                         "torch.distributed.all_reduce of the process group")
     ap.add_argument("--shuffle", choices=["hashed", "randperm"], default="hashed",
                     help="hashed: per-rank slice of a position-keyed bijection (default); randperm: torch.randperm "
                          "of the whole grid on every rank, the reference's literal call")
     args = ap.parse_args()
 
+    if args.overlap == "layer":
+        os.environ["WIRE_DP_OVERLAP"] = "layer"
+    elif args.overlap is not None:
+        os.environ["WIRE_DP_OVERLAP"] = "none"
+    if args.overlap == "micro" and args.micro_shards == 1:
+        args.micro_shards = 2
+    if args.dp_direct is not None:
+        os.environ["WIRE_DP_DIRECT"] = str(args.dp_direct)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))          # nothing above has touched the GPU
 
@@ -500,6 +616,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     final_loss = float(loss.item())
+    rccl = None
+    if tr.reducers[0].active:
+        rccl = rccl_probe(dev, tr)
 
     if rank == 0:
         n_gpu_batch = npts // world
@@ -566,7 +685,12 @@ def main():
                        "global_batch": npts, "parallelism": f"dp{world}", "micro_shards": args.micro_shards,
                        "shuffle": args.shuffle, "backend": backend if world > 1 else None,
                        "grad_allreduce": ("per layer, side stream, under the backward" if tr.overlap else
-                                          "whole buffer after the backward") if tr.reducers[0].active else None},
+                                          ("per micro-shard, side stream, under the next micro-shard" if args.micro_shards > 1
+                                           else "whole buffer after the backward")) if tr.reducers[0].active else None,
+                       "overlap": args.overlap or os.environ.get("WIRE_DP_OVERLAP", "none"),
+                       "dp_direct": int(tr.reducers[0].direct is not None),
+                       "rccl_nranks": (rccl or {}).get("rccl_nranks"), "rccl_device": (rccl or {}).get("rccl_device"),
+                       "rccl": {k: v for k, v in (rccl or {}).items() if k not in ("rccl_nranks", "rccl_device", "timeout")}},
             "roofline": {"bound": "mfma", "kernel": names[klass], "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "mfma_busy": mfma_busy, "pmc_source": pmc_note,
@@ -590,16 +714,26 @@ def main():
         }
         if hbm is not None:
             out["hbm"] = hbm
-        if world == 1 and not args.no_extras:
-            out["extras"] = extras(dev, lib)
+        # order of the slow legs: a CPU leg, the GPU extras, the remaining CPU legs -- GPU work in the MIDDLE of the run,
+        # so that an outside activity sampler meets it (the extras used to be 5 % at the very start)
         if world == 1 and not args.no_cpu_baseline:
             # N = 65 536 and 262 144, 4 x 256 and 4 x 181 complex (bounded: 3 + 1 iterations each)
             out["cpu_baseline"] = cpu_baseline(65536, 3)
-            out["cpu_baseline"]["more"] = {
-                "n262144_k256": cpu_baseline(262144, 2),
-                "n65536_k181_api_hidden_features_256": cpu_baseline(65536, 3, 256),
-                "n262144_k181_api_hidden_features_256": cpu_baseline(262144, 2, 256)}
+            out["cpu_baseline"]["more"] = {"n65536_k181_api_hidden_features_256": cpu_baseline(65536, 3, 256)}
+        if world == 1 and not args.no_extras:
+            out["extras"] = extras(dev, lib)
+            out["secondary"] = secondary(out["extras"])
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"]["more"]["n262144_k256"] = cpu_baseline(262144, 2)
+            out["cpu_baseline"]["more"]["n262144_k181_api_hidden_features_256"] = cpu_baseline(262144, 2, 256)
         print(json.dumps(out), flush=True)
+        if rccl is not None and rccl.get("rccl_nranks") not in (None, world):
+            print(f"error: RCCL reports {rccl.get('rccl_nranks')} ranks, --gpus {world}", file=sys.stderr)
+            sys.stdout.flush()
+            os._exit(4)
+    if rccl is not None and rccl.get("timeout"):
+        sys.stdout.flush()
+        os._exit(0)                                     # a stuck probe rendezvous must not hang the teardown
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -103,6 +103,8 @@ def _worker_rccl_direct(rank, world, port, out_dir, overlap="layer"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["WIRE_DP_FORCE"] = "1"
+    os.environ["WIRE_DP_DIRECT"] = "1"                 # opt-in since round 4 (default: the process group's all_reduce)
+    os.environ["WIRE_DP_CHECK"] = "2"                  # the replica check runs too (trivially true on one rank)
     os.environ["WIRE_DP_OVERLAP"] = overlap
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dev = torch.device("cuda", 0)

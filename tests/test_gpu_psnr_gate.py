@@ -1,12 +1,20 @@
-"""Quality gate of BASELINE.json's north_star ("PSNR within 0.1 dB of reference") at config-1 scale on the image the
-reference ships.
+"""Quality gate of BASELINE.json's north_star ("PSNR within 0.1 dB of reference") on the images the reference ships.
 
-tests/golden/psnr_parrot_cfg1.npz (tests/golden/make_psnr_golden.py, build container) holds the RGB of
-``data_noisy/parrot_noisy_T30.0_snr2.png`` (678 x 1020) and the trajectory of the REFERENCE's own model (``modules.wire.INR``
-imported from the reference, CPU fp32) through the loop of wire_image_denoise.py:104-178 -- 2 hidden layers x 128 features
-(K = 90), omega0 = 7, sigma0 = 6, Adam lr = 5e-3 min(1, maxpoints / HW), LambdaLR 0.1^(epoch / niters), maxpoints = 65 536
-(11 minibatches per epoch), torch.manual_seed(0) once before the model is built, ``torch.randperm(H W)`` per epoch -- for
-10 epochs, plus the same loop in fp64 (the yardstick for what two correct fp32 implementations may differ by).
+tests/golden/psnr_parrot_*.npz (tests/golden/make_psnr_golden.py, build container) hold an 8-bit RGB image of the reference
+and the trajectory of the REFERENCE's own model (``modules.wire.INR`` imported from the reference, CPU fp32) through the
+loop of wire_image_denoise.py:104-178 -- Adam lr = 5e-3 min(1, maxpoints / HW), LambdaLR 0.1^(epoch / niters), maxpoints =
+65 536 (11 minibatches per epoch of the 678 x 1020 image), torch.manual_seed(0) once before the model is built,
+``torch.randperm(H W)`` per epoch -- plus the same loop in fp64 (the yardstick for what two correct fp32 implementations may
+differ by):
+
+ * psnr_parrot_cfg1: BASELINE.json configs[0] -- 2 hidden layers x 128 features (K = 90), omega0 = 7, sigma0 = 6 -- on
+   ``data_noisy/parrot_noisy_T30.0_snr2.png`` for 100 epochs = 1100 optimizer steps (round 3: 10 epochs).  The fit target is
+   the noisy image itself (the clean one is git-ignored upstream), so the PSNR saturates at that target's noise floor,
+   17.26 dB;
+ * psnr_parrot_pub2x300: the net of the reference's published denoise result (2 x 300 -> K = 212, omega0 = 7, sigma0 = 8,
+   91 587 parameters, 29.70 dB: multiscale_results/denoise/T30.0_SNR2/Final/WIRE_s8_o7_LR5e3_E2000_2/metrics_table.md:3)
+   fitted for 30 epochs = 330 steps to the reconstruction that run stored (``Output_img.png`` beside the table: the one
+   clean parrot image the reference holds) -- the regime of the published number, about 25 dB after this schedule.
 
 Here the same loop runs on the MI355X through ``FusedTrainer.step(indices)`` with the regenerated permutations: the
 per-minibatch losses must follow the reference's, the per-epoch MSE of ``rec`` must follow it, and the final
@@ -25,10 +33,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def test_parrot_denoise_schedule_psnr_within_0p1_db_of_reference():
+@pytest.mark.parametrize("fixture", ["psnr_parrot_cfg1", "psnr_parrot_pub2x300"])
+def test_parrot_denoise_schedule_psnr_within_0p1_db_of_reference(fixture):
     from wire_amd.modules import models
     from wire_amd.trainer import FusedTrainer
-    z = np.load(os.path.join(GOLDEN, "psnr_parrot_cfg1.npz"), allow_pickle=False)
+    z = np.load(os.path.join(GOLDEN, fixture + ".npz"), allow_pickle=False)
     u8 = z["image_u8"]
     H, W, _ = u8.shape
     assert (H, W) == (678, 1020)
@@ -64,7 +73,7 @@ def test_parrot_denoise_schedule_psnr_within_0p1_db_of_reference():
     # the reference's own fp32-vs-fp64 drift on this schedule is the yardstick (+ a floor for the last fp32 bits)
     drift_ref = np.abs(ref_loss - l64) / l64
     drift = np.abs(losses - l64) / l64
-    print(f"PSNR build {psnr:.4f} dB  reference {float(z['psnr']):.4f} dB  (fp64 twin {float(z['psnr64']):.4f});  "
+    print(f"{fixture} ({niters} epochs, {len(losses)} steps): PSNR build {psnr:.4f} dB  reference {float(z['psnr']):.4f} dB  (fp64 twin {float(z['psnr64']):.4f});  "
           f"loss drift vs fp64: build max {drift.max():.2e}, reference max {drift_ref.max():.2e}")
     assert abs(psnr - float(z["psnr"])) < 0.1
     assert np.all(np.abs(losses - ref_loss) <= 1e-3 * ref_loss)            # the trajectories stay together ...

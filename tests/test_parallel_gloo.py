@@ -78,3 +78,26 @@ def test_sharded_gradient_equals_full_batch(tmp_path, B, bucket):
     g = wo.wire_backward(P, cache, gy, m["L"], m["om1"], m["om"], m["sc"])
     full = np.concatenate([_flat(g, list(P.keys())), [loss]])
     assert np.abs(red - full).max() <= 1e-12 * np.abs(full).max()
+
+
+def _check_worker(rank, world, port, diverge):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wire_amd.parallel import replicas_identical
+    flat = torch.linspace(-1, 1, 1001, dtype=torch.float32)
+    if diverge and rank == 1:
+        flat[517] = torch.nextafter(flat[517], torch.tensor(2.0))      # one bit in one parameter of one replica
+    same = replicas_identical(flat)
+    assert same == (not diverge), (rank, same)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("diverge", [False, True])
+def test_replica_check_sees_a_single_bit(diverge):
+    """WIRE_DP_CHECK (FusedTrainer): every rank learns whether all replicas hold the same parameter bits -- an
+    order-independent checksum through one MAX all-reduce; a one-ulp difference in one element of one rank shows."""
+    port = 31500 + (os.getpid() % 2000) + int(diverge)
+    mp.spawn(_check_worker, args=(2, port, diverge), nprocs=2, join=True)

@@ -59,9 +59,22 @@ typedef unsigned x2u32x2 __attribute__((ext_vector_type(2)));
 
 #define X2_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 
+// LDS-DMA of 16 bytes per lane (1 KB per wave instruction), as inline assembly rather than
+// __builtin_amdgcn_global_load_lds (round 4): with the builtin in a loop the compiler's wait-count pass degrades every
+// LDS-read wait of that loop to lgkmcnt(0) -- each fragment read then waits for all the reads issued after it (found with
+// the fused forward kernel, wire_fused.hip: fx_dma16; a 20-line kernel shows 14 x lgkmcnt(2) without the builtin and
+// 7 x lgkmcnt(0) with it).  The DMA is synchronised by hand in these kernels anyway (vmcnt + barrier).  "x2_dma_asm" = 0
+// (WIRE_X2_DMA_BUILTIN at build time) keeps the builtin for the A/B.
 WIRE_DEVINL void x2_dma16(const void* gsrc, unsigned char* lds_piece) {
+#ifdef WIRE_X2_DMA_BUILTIN
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
+#else
+  const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_piece;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(la) : "memory");
+#endif
 }
 
 // ---------------------------------------------------------------------------

@@ -50,29 +50,77 @@ class RcclDirect:
             l.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
             l.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
             l.ncclCommDestroy.argtypes = [C.c_void_p]
+            l.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+            l.ncclCommCuDevice.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
             l.ncclGetErrorString.restype = C.c_char_p
             l.ncclGetErrorString.argtypes = [C.c_int]
             cls._lib = l
         return cls._lib
 
     def __init__(self, device: torch.device, group: Optional[dist.ProcessGroup] = None):
-        l = self.lib()
+        """Collective: every rank of ``group`` must call this.  The set-up is SYMMETRIC: every rank sends and
+        receives the same messages whatever fails where --
+          1. each rank loads librccl and checks its device locally; the outcomes are agreed on (MIN all-reduce);
+          2. rank 0 draws the unique id and ALWAYS broadcasts status + 128 id bytes, also when drawing it failed;
+          3. only if every rank is still fine do all of them enter ``ncclCommInitRank`` (itself a rendezvous), and its
+             outcome is agreed on again;
+        any failure raises the same RuntimeError on every rank, so the caller's fallback is taken by all of them."""
+        self.comm = C.c_void_p()
+        self.device = device
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        uid = _NcclUniqueId()
-        if self.rank == 0:
-            self._check(l.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        # 128 bytes through the existing process group (device tensor for nccl, host tensor for gloo)
         on_dev = dist.get_backend(group) == "nccl"
-        t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone()
-        t = t.to(device) if on_dev else t
         src = dist.get_global_rank(group, 0) if group is not None else 0
+
+        def agree(ok: bool, what: str) -> None:
+            flag = torch.tensor([1.0 if ok else 0.0], device=device if on_dev else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if float(flag.item()) < 1.0:
+                raise RuntimeError(f"direct RCCL communicator: {what} failed on at least one rank")
+
+        err = None
+        l = None
+        try:
+            l = self.lib()
+            if device.type != "cuda":
+                raise RuntimeError("not a GPU device")
+        except Exception as e:                              # noqa: BLE001
+            err = e
+        agree(err is None, f"loading librccl ({err})")
+        uid = _NcclUniqueId()
+        msg = torch.zeros(129, dtype=torch.uint8)
+        if self.rank == 0:
+            rc = l.ncclGetUniqueId(C.byref(uid))
+            if rc == 0:
+                msg[0] = 1
+                msg[1:] = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8)
+        # status + 128 bytes through the existing process group (device tensor for nccl, host tensor for gloo)
+        t = msg.to(device) if on_dev else msg
         dist.broadcast(t, src=src, group=group)
-        C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
-        self.comm = C.c_void_p()
+        t = t.cpu()
+        if int(t[0]) != 1:
+            raise RuntimeError("direct RCCL communicator: ncclGetUniqueId failed on rank 0")
+        C.memmove(C.byref(uid), bytes(t[1:].numpy().tobytes()), 128)
         with torch.cuda.device(device):
-            self._check(l.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
-        self.device = device
+            rc = l.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank)
+        try:
+            agree(rc == 0, "ncclCommInitRank")
+        except RuntimeError:
+            if rc == 0:
+                self.close()
+            raise
+
+    def comm_count(self) -> int:
+        """Number of ranks RCCL itself reports for this communicator (ncclCommCount)."""
+        n = C.c_int(-1)
+        self._check(self.lib().ncclCommCount(self.comm, C.byref(n)), "ncclCommCount")
+        return int(n.value)
+
+    def comm_device(self) -> int:
+        """HIP device RCCL itself reports for this communicator (ncclCommCuDevice)."""
+        d = C.c_int(-1)
+        self._check(self.lib().ncclCommCuDevice(self.comm, C.byref(d)), "ncclCommCuDevice")
+        return int(d.value)
 
     @staticmethod
     def _check(rc: int, what: str) -> None:
@@ -111,6 +159,21 @@ def shard_weight(batch: int, world: int, rank: int) -> float:
     return (hi - lo) / float(batch) if batch > 0 else 0.0
 
 
+def replicas_identical(flat: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> bool:
+    """True when every rank holds the same bits in ``flat`` (float32): an order-independent 64-bit checksum of the bit
+    patterns, compared through one MIN and one MAX all-reduce.  One host sync -- the opt-in replica check of
+    FusedTrainer (WIRE_DP_CHECK=k: every k optimizer steps)."""
+    cs = flat.detach().contiguous().view(torch.int32).to(torch.int64).sum().reshape(1)
+    pair = torch.cat([cs, -cs])
+    if pair.is_cuda and dist.get_backend(group) == "gloo":
+        host = pair.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+        pair = host
+    else:
+        dist.all_reduce(pair, op=dist.ReduceOp.MAX, group=group)
+    return int(pair[0].item()) == -int(pair[1].item())      # max == min
+
+
 class FlatGradAllReducer:
     """All-reduce(SUM) of a flat gradient buffer, optionally in buckets issued
     on a side stream so that the collective of bucket i overlaps whatever the
@@ -146,27 +209,21 @@ class FlatGradAllReducer:
         if self.active and flat.is_cuda and use_side_stream and not self.stage_host:
             self.stream = torch.cuda.Stream(device=flat.device)
         self._pending: List = []
-        # RCCL backend, collective on the compute stream: ncclAllReduce straight from here (RcclDirect) instead of
-        # through the process group's own stream; WIRE_DP_DIRECT=0 keeps torch.distributed.all_reduce.  Any failure to
-        # set the communicator up falls back to the process group (every rank takes the same branch: the outcome is
-        # agreed on with a MIN all-reduce).
+        # RCCL backend: by default torch.distributed.all_reduce (the process group's own stream, two event hand-offs per
+        # collective: ~3 % of a step on one rank, tools/dp_overhead.sh).  WIRE_DP_DIRECT=1 issues ncclAllReduce straight
+        # from here on the compute stream (RcclDirect: 0 - 0.5 %) -- OPT-IN until a run with two or more ranks has been
+        # recorded (no builder session has had a second GPU).  RcclDirect's set-up is symmetric: a failure
+        # anywhere raises on every rank, and every rank falls back to the process group together.
         if (self.active and flat.is_cuda and not self.stage_host
-                and dist.get_backend(group) == "nccl" and os.environ.get("WIRE_DP_DIRECT", "1") != "0"):
+                and dist.get_backend(group) == "nccl" and os.environ.get("WIRE_DP_DIRECT", "0") == "1"):
             key = (flat.device.index, id(group))
             comm = FlatGradAllReducer._direct_comms.get(key)
             if comm is None:
-                ok = torch.ones(1, device=flat.device)
                 try:
-                    comm = RcclDirect(flat.device, group)
+                    comm = RcclDirect(flat.device, group)   # raises on EVERY rank or on none
                 except Exception as e:                      # noqa: BLE001 -- any failure means "use the process group"
                     import warnings
                     warnings.warn(f"direct RCCL communicator unavailable ({e}); using torch.distributed.all_reduce")
-                    ok.zero_()
-                    comm = None
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-                if float(ok.item()) < 1.0:
-                    if comm is not None:
-                        comm.close()
                     comm = None
                 FlatGradAllReducer._direct_comms[key] = comm if comm is not None else False
             self.direct = comm if comm else None

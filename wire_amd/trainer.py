@@ -32,7 +32,7 @@ import torch.distributed as dist
 from . import _lib
 from .modules._base import HipINR
 from .modules.utils import axis_tables
-from .parallel import FlatGradAllReducer, shard_bounds
+from .parallel import FlatGradAllReducer, replicas_identical, shard_bounds
 
 
 class FusedTrainer:
@@ -124,9 +124,25 @@ class FusedTrainer:
         # much as the whole latency-bound all-reduce they would hide.
         self.overlap = self.micro == 1 and os.environ.get("WIRE_DP_OVERLAP", "none") == "layer"
         self.reducers = [FlatGradAllReducer(g, group, use_side_stream=side or self.overlap) for g in self.gbuf]
-        self.overlap = self.overlap and self.reducers[0].active
+        # (host-staged exchange -- the gloo rehearsal with device gradients -- would block inside the announcement callback,
+        #  which must not wait for the device (include/wire_hip.h): one reduction after the backward instead)
+        self.overlap = self.overlap and self.reducers[0].active and not self.reducers[0].stage_host
         self._cb_err: Optional[BaseException] = None
-        self._ready_cb = _lib.GRAD_READY_FN(self._on_grad_ready)     # (kept alive with the trainer)
+        # the C callback only exists with the per-layer overlap, and holds the trainer weakly: no reference cycle, so
+        # `del trainer` releases the act / scratch / gradient buffers at once
+        self._ready_cb = None
+        if self.overlap:
+            import weakref
+            ref = weakref.ref(self)
+
+            def _cb(user, first, n):
+                tr = ref()
+                if tr is not None:
+                    tr._on_grad_ready(user, first, n)
+            self._ready_cb = _lib.GRAD_READY_FN(_cb)
+        # WIRE_DP_CHECK=k: every k optimizer steps the replicas compare a checksum of their parameters (one host sync);
+        # a divergence raises instead of training on silently
+        self.check_every = max(0, int(os.environ.get("WIRE_DP_CHECK", "0")))
         self._cap = 0
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self._hidx: Optional[torch.Tensor] = None
@@ -306,6 +322,9 @@ class FusedTrainer:
                                          self.current_lr(), self.betas[0], self.betas[1], self.eps,
                                          self.t), "adam")
         self.loss = gsum[self.count:self.count + 1].clone()   # the buffer is reused next step
+        if self.check_every and self.world > 1 and self.t % self.check_every == 0:
+            if not replicas_identical(self.flat, self.group):
+                raise RuntimeError(f"data-parallel replicas diverged at optimizer step {self.t} (WIRE_DP_CHECK)")
         return self.loss
 
     # ------------------------------------------------------------------ super-resolution step
