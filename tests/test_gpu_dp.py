@@ -56,7 +56,10 @@ def _worker(rank, world, port, micro, out_dir, hashed=False, overlap="layer"):
     model, tr = _make(dev, micro, seed=100 + rank if hashed else 0)
     assert tr.world == world and tr.rank == rank
     # one micro-shard: every layer's gradient slice is reduced as soon as wire_train_fwd_bwd_hooked announces it
-    assert tr.overlap == (micro == 1 and overlap == "layer")
+    # (two ranks on one card exchange through gloo, i.e. host-staged: there the per-layer overlap falls back to one
+    #  reduction after the backward -- a blocking host exchange may not run inside the announcement callback, ADVICE r03;
+    #  the overlap machinery itself runs on the RCCL communicator in test_direct_rccl_allreduce_... below)
+    assert tr.overlap == (micro == 1 and overlap == "layer" and not tr.reducers[0].stage_host)
     losses = _run(tr, dev, hashed)
     flat = tr.flat.detach().cpu().numpy()
     np.save(os.path.join(out_dir, f"flat_{rank}.npy"), flat)

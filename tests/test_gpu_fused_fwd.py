@@ -95,3 +95,70 @@ def test_fused_render_equals_model_call_and_covers_every_row():
         ref = model(coords[None])[0]
     assert relmax(out.cpu().numpy(), ref.cpu().numpy()) <= 2e-6
     assert torch.equal(out[:5000], ref[:5000])           # a tile of the fused kernel == the same rows of one big launch
+
+
+TRAIN_CASES = {
+    "siren_4x256": (dict(nonlin="siren", hidden_features=256, first_omega_0=30.0, hidden_omega_0=30.0), 4),
+    "gauss_3x256": (dict(nonlin="gauss", hidden_features=256, scale=10.0), 3),
+    "relu_4x256": (dict(nonlin="relu", hidden_features=256), 4),
+    "wire_k128_2x": (dict(nonlin="wire", hidden_features=182, first_omega_0=7.0, hidden_omega_0=7.0, scale=6.0), 2),
+    "siren_1x256": (dict(nonlin="siren", hidden_features=256, first_omega_0=30.0, hidden_omega_0=30.0), 1),
+}
+
+
+@pytest.mark.parametrize("case", list(TRAIN_CASES))
+def test_fused_training_forward_vs_layerwise_and_fp64_oracle(case):
+    """The TRAINING forward as one kernel (knob "fused_train"): FusedTrainer.step stores lin_l / out_l from inside
+    fused_fwd_kernel -- lin in the reference's units, out_0 fp32 + its maximum, the inner out_l as unscaled fp16 pairs (relu:
+    fp32 + maxima) -- and the unchanged final stage, data-gradient and weight-gradient kernels read them.  Loss, output and
+    every gradient against the layer-by-layer forward ("fused_train" = 0) and the fp64 oracle; ragged row count (the
+    kernel stores whole 128-row tiles: the padding rows of the act buffer take the overhang)."""
+    from _util import oracle_grads_chunked
+    from wire_amd import _lib
+    from wire_amd.modules import models
+    from wire_amd.trainer import FusedTrainer
+    kw, Ln = TRAIN_CASES[case]
+    kw = dict(kw)
+    kind = kw["nonlin"]
+    L = _lib.lib()
+    assert L.wire_tune_get(b"fused_train") == 1
+    grid = (131, 97)                                     # 12 707 rows: 99 workgroups and 35 rows
+    N = grid[0] * grid[1]
+    g = torch.Generator().manual_seed(9)
+    target = torch.rand(N, 3, generator=g)
+    perm = torch.randperm(N, generator=g)
+    res = {}
+    for knob in (1, 0):
+        _lib.check(L.wire_tune_set(b"fused_train", knob))
+        try:
+            torch.manual_seed(6)
+            model = models.get_INR(in_features=2, out_features=3, hidden_layers=Ln, **kw).to(DEV)
+            tr = FusedTrainer(model, grid, target, lr=0.0, keep_rec=True)
+            loss = tr.step(perm.to(DEV))
+            torch.cuda.synchronize()
+            res[knob] = (float(loss.item()), tr.flat_grad.cpu().numpy().copy(), tr.rec.cpu().numpy()[perm.numpy()].copy())
+            offsets = list(tr.offsets)
+        finally:
+            _lib.check(L.wire_tune_set(b"fused_train", 1))
+    assert not np.array_equal(res[0][1], res[1][1]), "the knob did not switch kernels"
+    P = params_np(model)
+    coords = wo.image_coords(*grid)[perm.numpy()]
+    tgt = target.numpy()[perm.numpy()]
+    om1, om, sc = kw.get("first_omega_0", 30.0), kw.get("hidden_omega_0", 30.0), kw.get("scale", 10.0)
+    masks = None
+    y64, l64, g64 = oracle_grads_chunked(kind, P, coords, tgt, Ln, om1, om, sc, True)
+    y32, l32, g32 = oracle_grads_chunked(kind, P, coords, tgt, Ln, om1, om, sc, False)
+    err_y = relmax(y32, y64)
+    within_ref(relmax(res[1][2], y64), err_y, f"fused_train[{case}] y")
+    assert abs(res[1][0] - l64) <= (2 * abs(l32 - l64) / l64 + 1e-5) * l64
+    names = [k for k in model.state_dict().keys() if "omega_0" not in k and "scale_0" not in k]
+    for name, off in zip(names, offsets):
+        ref = wo.as_real_pairs(g64[name]).astype(np.float64).ravel()
+        ref32 = wo.as_real_pairs(g32[name]).astype(np.float64).ravel()
+        mine, lay = res[1][1][off:off + ref.size], res[0][1][off:off + ref.size]
+        if kind == "relu" or name == f"net.{Ln + 1}.bias":
+            # relu: a gradient sum moves by whole terms where lin is round-off (test_gpu_timed_kernels.py: forced decisions);
+            # the final bias is the mean of dL/dy, a few nearly cancelling numbers: both against the layer-by-layer path only
+            assert relmax(mine, lay) <= 2e-5, f"{case} {name}"
+        else:
+            within_ref(relmax(mine, ref), relmax(ref32, ref), f"fused_train[{case}] grad {name}")

@@ -501,6 +501,9 @@ def test_recompute_out_is_bit_identical(nonlin):
     L = _lib.lib()
     assert L.wire_tune_get(b"recompute_out") == 1
     res = []
+    # (the knob also decides whether the training forward may run as one kernel, wire_fused.hip -- other arithmetic; this
+    #  test is about the layer-by-layer kernels: "fused_train" = 0)
+    _lib.check(L.wire_tune_set(b"fused_train", 0))
     for knob in (0, 1):
         _lib.check(L.wire_tune_set(b"recompute_out", knob))
         try:
@@ -521,6 +524,8 @@ def test_recompute_out_is_bit_identical(nonlin):
             res.append((loss.clone(), tr.rec.clone(), tr.flat_grad.clone()))
         finally:
             _lib.check(L.wire_tune_set(b"recompute_out", 1))
+            if knob == 1:
+                _lib.check(L.wire_tune_set(b"fused_train", 1))
     assert torch.equal(res[0][0], res[1][0])
     assert torch.equal(res[0][1], res[1][1])
     assert torch.equal(res[0][2], res[1][2])
@@ -545,6 +550,7 @@ def test_presplit_activations_agree_with_fp32_activations(nonlin, hf, om_sc):
     L = _lib.lib()
     assert L.wire_tune_get(b"split_out") == 1
     res = []
+    _lib.check(L.wire_tune_set(b"fused_train", 0))      # the layer-by-layer kernels' two formats (wire_fused.hip has its own test)
     for knob in (0, 1):
         _lib.check(L.wire_tune_set(b"split_out", knob))
         try:
@@ -568,6 +574,8 @@ def test_presplit_activations_agree_with_fp32_activations(nonlin, hf, om_sc):
             res.append((loss.clone(), tr.rec.clone(), tr.flat_grad.clone(), out1))
         finally:
             _lib.check(L.wire_tune_set(b"split_out", 1))
+            if knob == 1:
+                _lib.check(L.wire_tune_set(b"fused_train", 1))
     engaged = om_sc is None or om_sc[0] / om_sc[1] <= 3.33
     assert torch.equal(res[0][3], res[1][3]) != engaged, "format of the stored out_1 with / without split_out"
     assert abs(float(res[0][0]) - float(res[1][0])) <= 1e-6 * abs(float(res[0][0]))
@@ -589,6 +597,7 @@ def test_operand_load_editions_are_bit_identical(nonlin, hf):
     L = _lib.lib()
     assert L.wire_tune_get(b"x2_amode") == 2
     res = []
+    _lib.check(L.wire_tune_set(b"fused_train", 0))      # the forward GEMMs whose operand path the knob selects must run
     for mode in (2, 1, 0):
         _lib.check(L.wire_tune_set(b"x2_amode", mode))
         try:
@@ -606,6 +615,8 @@ def test_operand_load_editions_are_bit_identical(nonlin, hf):
             res.append((loss.clone(), tr.rec.clone(), tr.flat_grad.clone()))
         finally:
             _lib.check(L.wire_tune_set(b"x2_amode", 2))
+            if mode == 0:
+                _lib.check(L.wire_tune_set(b"fused_train", 1))
     for other in res[1:]:
         assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1]) and torch.equal(res[0][2], other[2])
     assert float(res[0][2].abs().max()) > 0

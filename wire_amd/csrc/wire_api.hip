@@ -259,19 +259,22 @@ inline int64_t first_native_off(const Plan& p, int q) {
 
 // activation carve (floats)
 struct ActLayout {
-  int64_t pe, out0, lin0, lin1, total;   // out_l = out0 + l*n*P ; lin_l = lin1 + (l-1)*n*Pl
+  int64_t pe, out0, lin0, lin1, total;   // out_l = out0 + l*np*P ; lin_l = lin1 + (l-1)*np*Pl
   int64_t ping, pong;                    // inference
   int64_t amax;                          // max |out_l| slots, WIRE_AMAX_SLOTS per layer l = 0..L (2 x fp16 GEMMs)
+  int64_t np;                            // rows each saved buffer is spaced by: n rounded up to 128 -- the fused training
+                                         // forward (wire_fused.hip) stores whole 128-row workgroup tiles unconditionally
 };
 ActLayout act_layout(const Plan& p, int64_t n, int save) {
   ActLayout a{};
   int64_t off = 0;
+  a.np = (n + 127) / 128 * 128;
   a.amax = off; off += (int64_t)(p.L + 2) * WIRE_AMAX_SLOTS;
   a.pe = off; if (p.first_gemm) off += n * p.Pin0;
   if (save) {
-    a.out0 = off; off += n * p.P * (p.L + 1);
-    a.lin0 = off; if (!p.cplx) off += n * p.P;
-    a.lin1 = off; off += n * p.Pl * p.L;
+    a.out0 = off; off += a.np * p.P * (p.L + 1);
+    a.lin0 = off; if (!p.cplx) off += a.np * p.P;
+    a.lin1 = off; off += a.np * p.Pl * p.L;
   } else {
     a.ping = off; off += n * p.P;
     a.pong = off; off += n * p.P;
@@ -339,10 +342,23 @@ bool use_x2(const Plan& p, int64_t n) {
 //    fp16 range: sine and Gaussian <= 1; Gabor |exp(j w lin - s^2 |lin|^2)| = exp(-w v - s^2 (u^2 + v^2)) <= exp(w^2 / 4 s^2),
 //    attained at lin = -j w / 2 s^2 -- accepted up to 16 (w / s <= 3.33: every configuration of the reference's scripts;
 //    beyond it the maximum is tracked on the device as before).  bound < 2^e  ->  scale 2^(15 - e): |out| scale < 2^15.
+float fused_act_scale(const Plan& p);
+// The training forward of this call runs as ONE kernel (wire_fused.hip) that stores lin_l / out_l on the way: the shapes
+// that have a kernel (256-feature real nets; wire at P = 192 / 256 -- P = 384 spills in its storing edition), the 2 x fp16
+// family with its pre-split activations and recompute_out (the formats that kernel writes), a bound on the activations (all
+// kinds but relu).  Decides the FORMAT of the stored out_l (pre-split at scale 1), so the backward asks the same question.
+bool fused_train_applies(const Plan& p, int64_t n) {
+  if (!fused_train_enabled() || p.off_fx < 0 || p.L < 1 || p.L > 8 || p.first_gemm) return false;
+  if (!use_x2(p, n) || !gemmx2_tn_applies(p.Pl, p.P) || !g_split_out || !g_recompute_out) return false;
+  if (p.kind == WIRE_KIND_WIRE && p.P > 256) return false;
+  if (p.kind != WIRE_KIND_RELU && fused_act_scale(p) == 0.f) return false;
+  return fused_pre_scale(p.kind, p.w1, p.s) > 0.f && fused_pre_scale(p.kind, p.w, p.s) > 0.f;
+}
 float out_split_scale(const Plan& p, int64_t n, int l) {
   if (!g_split_out || l < 1 || l >= p.L || p.kind == WIRE_KIND_RELU) return 0.f;
   if (!use_x2(p, n) || !gemmx2_tn_applies(p.Pl, p.P)) return 0.f;
   if (!g_recompute_out && p.kind != WIRE_KIND_SIREN) return 0.f;
+  if (fused_train_applies(p, n)) return 1.f;               // the fused forward splits its bounded activations unscaled
   double bound = 1.0;
   if (p.cplx) {
     if (!(p.s > 0.f)) return 0.f;
@@ -418,7 +434,8 @@ extern "C" int wire_blocked_width(int K) { return rup(2 * K, 64); }
 extern "C" int64_t wire_act_out_offset(const wire_net_desc* d, int64_t n, int layer) {
   Plan p; if (make_plan(d, p)) return WIRE_ERR_ARG;
   if (n < 0 || layer < 0 || layer > p.L) return fail(WIRE_ERR_ARG, "bad argument to wire_act_out_offset");
-  return act_layout(p, n, 1).out0 + (int64_t)layer * n * p.P;
+  const ActLayout a = act_layout(p, n, 1);
+  return a.out0 + (int64_t)layer * a.np * p.P;
 }
 
 // ---------------------------------------------------------------------------
@@ -547,12 +564,36 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
   unsigned* const amax = reinterpret_cast<unsigned*>(A + a.amax);            // slots of out_l at amax + 64 l
   auto wamax = [&](int l) { return reinterpret_cast<const unsigned*>(packed + p.off_wamax + (int64_t)l * WIRE_AMAX_SLOTS); };
   if (x2) HIPCHK(hipMemsetAsync(amax, 0, (size_t)(p.L + 2) * WIRE_AMAX_SLOTS * sizeof(unsigned), s));
-  auto out_l = [&](int l) { return save_for_bwd ? A + a.out0 + (int64_t)l * n * p.P
+  if (save_for_bwd && !do_final && p.O <= 4 && fused_train_applies(p, n) &&
+      (skip_last_out || p.kind == WIRE_KIND_RELU)) {
+    // training forward of wire_train_fwd_bwd: the hidden layers in one kernel that stores lin_l (not relu), out_0 (fp32 +
+    // its maximum), out_1 .. out_{L-1} (pre-split pairs; relu: fp32 + maxima, and out_L) -- what the fused final stage,
+    // the data-gradient epilogues and the weight-gradient GEMMs of mlp_bwd_core read (wire_fused.hip)
+    FusedFwdParams fp;
+    fp.coords = coords; fp.n = n;
+    fp.W0 = packed + first_native_off(p, 0); fp.b0 = packed + first_native_off(p, 1);
+    fp.wimg = reinterpret_cast<const unsigned char*>(packed + p.off_fx);
+    fp.bias = packed + p.off_bias[1]; fp.bias_stride = p.L >= 2 ? p.off_bias[2] - p.off_bias[1] : 0;
+    fp.wamax = reinterpret_cast<const unsigned*>(packed + p.off_wamax) + WIRE_AMAX_SLOTS; fp.wamax_stride = WIRE_AMAX_SLOTS;
+    fp.D = p.D; fp.K = p.K; fp.L = p.L; fp.O = p.O; fp.w1 = p.w1; fp.w = p.w; fp.s = p.s;
+    fp.c_first = fused_pre_scale(p.kind, p.w1, p.s); fp.c_hidden = fused_pre_scale(p.kind, p.w, p.s);
+    fp.k2_first = p.s * p.s * 1.44269502f / (fp.c_first * fp.c_first);
+    fp.k2 = p.s * p.s * 1.44269502f / (fp.c_hidden * fp.c_hidden);
+    fp.inv_c_first = 1.f / fp.c_first; fp.inv_c_hidden = 1.f / fp.c_hidden;
+    fp.lin0 = p.cplx ? nullptr : A + a.lin0;
+    fp.lin = p.kind == WIRE_KIND_RELU ? nullptr : A + a.lin1; fp.lin_stride = a.np * p.Pl;
+    fp.out = A + a.out0; fp.out_stride = a.np * p.P;
+    fp.amax_out = amax;
+    ProfScope ps(s, 0, 2.0 * n * p.Pl * p.P * p.L);
+    HIPCHK(launch_fused_fwd(s, p.kind, p.P, fp));
+    return WIRE_OK;
+  }
+  auto out_l = [&](int l) { return save_for_bwd ? A + a.out0 + (int64_t)l * a.np * p.P
                                                 : A + ((l & 1) ? a.pong : a.ping); };
   auto lin_l = [&](int l) -> float* {
     // relu: out = max(lin, 0) carries everything its backward needs (lin > 0 <=> out > 0): lin is never written
     if (!save_for_bwd || p.kind == WIRE_KIND_RELU) return nullptr;
-    return l == 0 ? A + a.lin0 : A + a.lin1 + (int64_t)(l - 1) * n * p.Pl;
+    return l == 0 ? A + a.lin0 : A + a.lin1 + (int64_t)(l - 1) * a.np * p.Pl;
   };
   // ---- layer 0
   if (p.first_gemm) {
@@ -634,8 +675,8 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
   hipStream_t s = (hipStream_t)stream;
   const float* A = (const float*)act;
   float* Sx = (float*)scratch;
-  auto out_l = [&](int l) { return A + a.out0 + (int64_t)l * n * p.P; };
-  auto lin_l = [&](int l) { return l == 0 ? A + a.lin0 : A + a.lin1 + (int64_t)(l - 1) * n * p.Pl; };
+  auto out_l = [&](int l) { return A + a.out0 + (int64_t)l * a.np * p.P; };
+  auto lin_l = [&](int l) { return l == 0 ? A + a.lin0 : A + a.lin1 + (int64_t)(l - 1) * a.np * p.Pl; };
   float* gcur = Sx + sc.ga;
   float* gnext = Sx + sc.gb;
   const bool x2 = use_x2(p, n);
@@ -848,11 +889,11 @@ extern "C" int wire_train_fwd_bwd_hooked(void* stream, const wire_net_desc* d, c
     // final linear forward + MSE (loss, rec) + final linear backward + Gabor gradient of layer L:
     // one pass over out_L / lin_L instead of three
     ProfScope ps(s, 3, 0);
-    const float* linL = p.kind == WIRE_KIND_RELU ? nullptr : A + a.lin1 + (int64_t)(p.L - 1) * n * p.Pl;
+    const float* linL = p.kind == WIRE_KIND_RELU ? nullptr : A + a.lin1 + (int64_t)(p.L - 1) * a.np * p.Pl;
     const bool x2 = use_x2(p, n);
     unsigned* const gamax = reinterpret_cast<unsigned*>(Sx + sc.gamax);
     if (x2) HIPCHK(hipMemsetAsync(gamax, 0, (size_t)(p.L + 2) * WIRE_AMAX_SLOTS * sizeof(unsigned), s));
-    HIPCHK(launch_final_fused(s, p.kind, recomp ? nullptr : A + a.out0 + (int64_t)p.L * n * p.P, linL, n, p.P, p.O,
+    HIPCHK(launch_final_fused(s, p.kind, recomp ? nullptr : A + a.out0 + (int64_t)p.L * a.np * p.P, linL, n, p.P, p.O,
                               p.K, packed + p.off_wf, packed + p.off_bf, target, idx, first, weight,
                               p.w, p.s, y, rec, Sx + sc.ga, Sx + sc.fpw, Sx + sc.fpb, Sx + sc.crp, loss_out,
                               x2 ? gamax + p.L * WIRE_AMAX_SLOTS : nullptr));

@@ -161,6 +161,13 @@ struct FxCtx {
   const float* swf;           // LDS: final image [4][P]
   int t, T, buf;              // weight stream: next stage to consume, number of stages, its ring buffer
   float inv_prev;             // 1 / (s_A s_B) of the accumulators in the source set
+  // training forward: where the layer in production (l_src) is stored -- row pointers of THIS lane (row * P applied)
+  float* st_lin;              // lin_{l_src} [n][P] fp32, null = not stored
+  float* st_out;              // out_{l_src} [n][P]: fp32 (st_split = false) or pre-split pairs (wire_dev.h: wire_store_out4, scale 1)
+  bool st_split;
+  float st_inv_c;             // 1 / c: lin is stored in the reference's units
+  float amx;                  // max |out| of this wave's fp32-stored activations (the consumer GEMM's operand scale)
+  int ys;                     // vector-memory operations issued since the last weight-stream issue (stores: counted waits)
 };
 
 template <int NB, int RING>
@@ -176,12 +183,26 @@ WIRE_DEVINL void fx_issue(const FusedFwdParams& fp, const FxCtx& c, int t, int b
 // proves free (every wave has consumed stage c.t - 1) is refilled with stage c.t + RING - 1
 // (ABL: timing probes of the harness build -- results wrong -- bit 0 no producer, 1 no fragment reads, 2 no weight stream
 //  after the prologue, 3 no barrier; 0 in the product)
+// s_waitcnt vmcnt(n) for a value that is a constant only after unrolling (the immediate must be a literal)
+WIRE_DEVINL void fx_wait_vm(const int n) {
+#define FX_VM_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n < 0 ? 0 : (n > 24 ? 24 : n)) {
+    FX_VM_CASE(0) FX_VM_CASE(1) FX_VM_CASE(2) FX_VM_CASE(3) FX_VM_CASE(4) FX_VM_CASE(5) FX_VM_CASE(6) FX_VM_CASE(7)
+    FX_VM_CASE(8) FX_VM_CASE(9) FX_VM_CASE(10) FX_VM_CASE(11) FX_VM_CASE(12) FX_VM_CASE(13) FX_VM_CASE(14) FX_VM_CASE(15)
+    FX_VM_CASE(16) FX_VM_CASE(17) FX_VM_CASE(18) FX_VM_CASE(19) FX_VM_CASE(20) FX_VM_CASE(21) FX_VM_CASE(22) FX_VM_CASE(23)
+    default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+  }
+#undef FX_VM_CASE
+}
+// `younger` = vector-memory operations that were CERTAINLY issued after the pieces of stage c.t (the training forward's
+// stores and, with RING = 3, the pieces of stage c.t + 1): the wait may leave exactly those in flight.  Never more than were
+// issued -- a count that is too high would let a piece of stage c.t stay in flight.
 template <int NB, int RING, int ABL>
-WIRE_DEVINL void fx_stage_top(const FusedFwdParams& fp, FxCtx& c) {
+WIRE_DEVINL void fx_stage_top(const FusedFwdParams& fp, FxCtx& c, const int younger_stores) {
   constexpr int PIECES = NB / 4;
   if constexpr (!(ABL & 4)) {
-    if (RING == 3 && c.t + 1 < c.T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (RING == 3 && c.t + 1 < c.T) fx_wait_vm(PIECES + younger_stores);
+    else fx_wait_vm(younger_stores);
   }
   if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
   if (c.t + RING - 1 < c.T) {
@@ -266,17 +287,28 @@ template <int KIND, int NB> constexpr int fx_nparts() { return FxKind<KIND>::CPL
 //   real nets: two parts per stage (q = 2 + 2 j + i, i = cb / (NB / 2)), 7 steps each: lin | act 0..3 | split 01 | split 23
 //   wire:      one part per stage (q = 2 + j), 9 steps: lin | gabor 0..3 | split re01 | re23 | im01 | im23
 // `w` holds the part in flight: real [lin, out]; wire [u, v, o_re, o_im].
-template <int KIND, int NB, bool FROM_COORDS>
-WIRE_DEVINL void fx_slice(const FusedFwdParams& fp, const FxCtx& c, const f32x4 (&src)[NB], const int l_src,
-                          const float a_scale, const int j, const int cb, f32x4 (&w)[4], fx_u32x4 (&Fh)[NB / 2],
-                          fx_u32x4 (&Fl)[NB / 2]) {
+// TRAIN: the part is also STORED for the backward -- lin (in the reference's units) at its pre-activation step, out after
+// its last activation (fp32) or after its last split (the very registers of the fragment: wire_store_out4's format at scale
+// 1).  Stores are unconditional (rows beyond n land in the padding rows of the act buffer: wire_api.hip act_layout): their
+// number per stage is what the counted wait of the weight stream relies on.  Returns the number of stores it issued.
+template <int KIND, int NB, bool FROM_COORDS, bool TRAIN>
+WIRE_DEVINL int fx_slice(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)[NB], const int l_src,
+                         const float a_scale, const int j, const int cb, f32x4 (&w)[4], fx_u32x4 (&Fh)[NB / 2],
+                         fx_u32x4 (&Fl)[NB / 2]) {
   constexpr bool CPLX = FxKind<KIND>::CPLX;
   constexpr int P = 16 * NB, PF = CPLX ? P / 2 : P, NP = fx_nparts<KIND, NB>();
+  // what a training forward stores of the layer in production (compile-time: the store count per stage is part of the
+  // weight stream's wait): lin unless relu / wire's real layer 0; out fp32 for layer 0 and relu, else the split pairs
+  constexpr bool ST_LIN = TRAIN && KIND != NK_RELU && (!FROM_COORDS || !CPLX);
+  constexpr bool ST_F32 = TRAIN && (KIND == NK_RELU || FROM_COORDS);
+  constexpr bool ST_SPLIT = TRAIN && !ST_F32;
   if constexpr (CPLX) {
     constexpr int ST = NB / 9;                            // block stride between steps
     const int q = 2 + j;
-    if (q >= NP || cb % ST != 0 || cb / ST > 8) return;
+    if (q >= NP || cb % ST != 0 || cb / ST > 8) return 0;
     const int k = cb / ST, G = q >> 1, b = q & 1;
+    const int col = 64 * G + 16 * b + 4 * c.g;            // re column of the part; im = + 32
+    int stores = 0;
     if (k == 0) {
       if constexpr (FROM_COORDS) {
         const int f0 = 32 * G + 16 * b + 4 * c.g;
@@ -297,27 +329,53 @@ WIRE_DEVINL void fx_slice(const FusedFwdParams& fp, const FxCtx& c, const f32x4 
           w[1][e] = __builtin_fmaf(src[4 * G + 2 + b][e], c.inv_prev, b_im[e]);
         }
       }
+      if constexpr (ST_LIN) {
+        f32x4 lu, lv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lu[e] = w[0][e] * c.st_inv_c; lv[e] = w[1][e] * c.st_inv_c; }
+        *reinterpret_cast<f32x4*>(c.st_lin + col) = lu;
+        *reinterpret_cast<f32x4*>(c.st_lin + col + 32) = lv;
+        stores += 2;
+      }
     } else if (k <= 4) {
       const int e = k - 1;
       float a, bq;
       fx_gabor(w[0][e], w[1][e], FROM_COORDS ? fp.k2_first : fp.k2, a, bq);
       w[2][e] = a; w[3][e] = bq;
+      if constexpr (ST_F32) {
+        if (k == 4) {
+          *reinterpret_cast<f32x4*>(c.st_out + col) = w[2];
+          *reinterpret_cast<f32x4*>(c.st_out + col + 32) = w[3];
+          stores += 2;
+#pragma unroll
+          for (int x = 0; x < 4; ++x) c.amx = __builtin_fmaxf(c.amx, __builtin_fmaxf(__builtin_fabsf(w[2][x]), __builtin_fabsf(w[3][x])));
+        }
+      }
     } else {
       const int im = (k - 5) >> 1, pr = (k - 5) & 1;      // re / im plane, element pair
       unsigned h, lo;
       fx_split_pair<KIND>(w[2 + im][2 * pr], w[2 + im][2 * pr + 1], a_scale, h, lo);
       Fh[2 * G + im][2 * b + pr] = h;
       Fl[2 * G + im][2 * b + pr] = lo;
+      if constexpr (ST_SPLIT) {
+        if (pr == 1) {
+          *reinterpret_cast<fx_u32x4*>(c.st_out + col + 32 * im) =
+              fx_u32x4{Fh[2 * G + im][2 * b], Fh[2 * G + im][2 * b + 1], Fl[2 * G + im][2 * b], Fl[2 * G + im][2 * b + 1]};
+          stores += 1;
+        }
+      }
     }
+    return stores;
   } else {
     constexpr int ACT = FxKind<KIND>::ACT;
     constexpr int HB = NB / 2;                            // blocks per part
     static_assert(CPLX || HB >= 7, "seven producer steps per part");
     const int i = cb / HB, k = cb % HB;
     const int q = 2 + 2 * j + i;
-    if (q >= NP || k > 6) return;
+    if (q >= NP || k > 6) return 0;
+    const int col = 16 * q + 4 * c.g;
+    int stores = 0;
     if (k == 0) {
-      const int col = 16 * q + 4 * c.g;
       if constexpr (FROM_COORDS) {
         f32x4 lin = *reinterpret_cast<const f32x4*>(c.sb0 + col);
 #pragma unroll
@@ -332,15 +390,38 @@ WIRE_DEVINL void fx_slice(const FusedFwdParams& fp, const FxCtx& c, const f32x4 
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[0][e] = __builtin_fmaf(src[q][e], c.inv_prev, bv[e]);
       }
+      if constexpr (ST_LIN) {
+        f32x4 lu;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lu[e] = w[0][e] * c.st_inv_c;
+        *reinterpret_cast<f32x4*>(c.st_lin + col) = lu;
+        stores += 1;
+      }
     } else if (k <= 4) {
       w[1][k - 1] = fx_act<ACT>(w[0][k - 1]);
+      if constexpr (ST_F32) {
+        if (k == 4) {
+          *reinterpret_cast<f32x4*>(c.st_out + col) = w[1];
+          stores += 1;
+#pragma unroll
+          for (int x = 0; x < 4; ++x) c.amx = __builtin_fmaxf(c.amx, __builtin_fabsf(w[1][x]));
+        }
+      }
     } else {
       const int pr = k - 5;
       unsigned h, lo;
       fx_split_pair<KIND>(w[1][2 * pr], w[1][2 * pr + 1], a_scale, h, lo);
       Fh[q >> 1][2 * (q & 1) + pr] = h;
       Fl[q >> 1][2 * (q & 1) + pr] = lo;
+      if constexpr (ST_SPLIT) {
+        if (pr == 1) {
+          const int jj = q >> 1, bb = q & 1;
+          *reinterpret_cast<fx_u32x4*>(c.st_out + col) = fx_u32x4{Fh[jj][2 * bb], Fh[jj][2 * bb + 1], Fl[jj][2 * bb], Fl[jj][2 * bb + 1]};
+          stores += 1;
+        }
+      }
     }
+    return stores;
   }
 }
 
@@ -367,10 +448,23 @@ WIRE_DEVINL float fx_wave_scale(const FusedFwdParams& fp, const FxCtx& c, const 
 // hidden layer l (1 .. L):  dst = h_{l-1} W_l^T  with the operands' scales still on it; h_{l-1} comes from the coordinates
 // (l = 1) or from `src`, the accumulators of layer l - 1.  During the MFMAs of stage j the vector unit produces what stage
 // j + 1 (real nets: parts 2 j + 2, 2 j + 3) or the stage pair after the current one (wire: part j + 2) will consume.
-template <int KIND, int NB, int RING, bool FROM_COORDS, int ABL>
+template <int KIND, int NB, int RING, bool FROM_COORDS, int ABL, bool TRAIN>
 WIRE_DEVINL void fx_layer(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)[NB], f32x4 (&dst)[NB], const int l) {
   constexpr bool CPLX = FxKind<KIND>::CPLX;
-  constexpr int S = NB / 2, STAGE = NB * 2048;
+  constexpr int S = NB / 2, STAGE = NB * 2048, P = 16 * NB;
+  if constexpr (TRAIN) {
+    // layer l - 1 is produced (and stored) under this layer's MFMAs: lin_{l-1} (real nets but relu: also lin_0; wire: l - 1
+    // >= 1), out_{l-1} fp32 for layer 0 and for relu, pre-split for the inner layers of the other kinds
+    const size_t ro = (size_t)c.row * P;
+    const int ls = l - 1;
+    c.st_lin = nullptr;
+    if (KIND != NK_RELU && (!FROM_COORDS || !CPLX))
+      c.st_lin = (FROM_COORDS ? fp.lin0 : fp.lin + (size_t)(ls - 1) * fp.lin_stride) + ro;
+    c.st_out = fp.out + (size_t)ls * fp.out_stride + ro;
+    c.st_split = KIND != NK_RELU && !FROM_COORDS;
+    c.st_inv_c = ls == 0 ? fp.inv_c_first : fp.inv_c_hidden;
+    c.amx = 0.f;
+  }
   float sA = 1.f, invA = 1.f;                          // (bounded activations are split unscaled)
   if constexpr (KIND == NK_RELU) sA = fx_wave_scale<KIND, NB, FROM_COORDS>(fp, c, src, l - 1, invA);
   float sB, invB;
@@ -379,13 +473,18 @@ WIRE_DEVINL void fx_layer(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)
   fx_u32x4 Fh[S], Fl[S];
   f32x4 w[4];
   // parts 0 and 1 (what stage 0 -- wire: stages 0 and 1 -- consumes) before the first stage
+  // ys[0] / ys[1]: stores issued since the last / the last but one weight-stream issue (the counted wait of fx_stage_top)
+  int ys0 = c.ys, ys1 = 0;
 #pragma unroll
   for (int jj = (CPLX ? -2 : -1); jj < 0; ++jj)
 #pragma unroll
-    for (int cb = 0; cb < NB; ++cb) fx_slice<KIND, NB, FROM_COORDS>(fp, c, src, l - 1, sA, jj, cb, w, Fh, Fl);
+    for (int cb = 0; cb < NB; ++cb) ys0 += fx_slice<KIND, NB, FROM_COORDS, TRAIN>(fp, c, src, l - 1, sA, jj, cb, w, Fh, Fl);
 #pragma unroll
   for (int j = 0; j < S; ++j) {
-    fx_stage_top<NB, RING, ABL>(fp, c);
+    // RING 3: the pieces of stage t were issued two tops ago -- younger: the stores since then (ys1 + ys0) and the pieces of
+    // stage t + 1 (added in fx_stage_top); RING 2: one top ago -- younger: ys0
+    fx_stage_top<NB, RING, ABL>(fp, c, RING == 3 ? ys1 + ys0 : ys0);
+    ys1 = ys0; ys0 = 0;
     const unsigned char* Sb = c.ring + c.buf * STAGE + c.lane * 16;
     const fx_f16x8 ah = __builtin_bit_cast(fx_f16x8, Fh[j]), al = __builtin_bit_cast(fx_f16x8, Fl[j]);
     // weight fragments FX_PFD blocks ahead, in a rotating set of registers
@@ -408,13 +507,54 @@ WIRE_DEVINL void fx_layer(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)
       else FX_MFMA(xl, ah, dst[cb]);
       FX_MFMA(xh, al, dst[cb]);
       FX_MFMA(xh, ah, dst[cb]);
-      if constexpr (!(ABL & 1)) fx_slice<KIND, NB, FROM_COORDS>(fp, c, src, l - 1, sA, j, cb, w, Fh, Fl);
+      if constexpr (!(ABL & 1)) ys0 += fx_slice<KIND, NB, FROM_COORDS, TRAIN>(fp, c, src, l - 1, sA, j, cb, w, Fh, Fl);
       __builtin_amdgcn_sched_barrier(0);
     }
     c.t += 1;
     c.buf = c.buf + 1 == RING ? 0 : c.buf + 1;
   }
+  // (what the next layer's first wait may count: only the stores since the LAST issue -- the one before it lies two tops
+  //  back by then; RING 3 looks two tops back, so it also needs ys1 of the last stage: both are 0 there, the last stages of
+  //  a layer produce nothing)
+  c.ys = ys0;
   c.inv_prev = invA * invB;
+  if constexpr (TRAIN) {
+    // max |out_{l-1}| of the fp32-stored activations for the GEMMs that read them as operands (weight gradient)
+    if (!c.st_split && fp.amax_out) wire_amax_publish(fp.amax_out + (size_t)(l - 1) * WIRE_AMAX_SLOTS, c.amx, c.lane);
+  }
+}
+
+// training forward, after the last hidden layer: lin_L (and relu's out_L, which its backward reads) from the accumulators
+template <int KIND, int NB>
+WIRE_DEVINL void fx_tail_train(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)[NB]) {
+  constexpr bool CPLX = FxKind<KIND>::CPLX;
+  constexpr int P = 16 * NB;
+  const size_t ro = (size_t)c.row * P;
+  float* lin = KIND == NK_RELU ? nullptr : fp.lin + (size_t)(fp.L - 1) * fp.lin_stride + ro;
+  float* out = KIND == NK_RELU ? fp.out + (size_t)fp.L * fp.out_stride + ro : nullptr;
+  float amx = 0.f;
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) {
+    const int col = 16 * cb + 4 * c.g;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(c.sbias + (fp.L - 1) * P + col);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(src[cb][e], c.inv_prev, bv[e]);
+    if (lin) {
+      f32x4 lu;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lu[e] = r[e] * fp.inv_c_hidden;
+      *reinterpret_cast<f32x4*>(lin + col) = lu;
+    }
+    if (out) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = r[e] > 0.f ? r[e] : 0.f; amx = __builtin_fmaxf(amx, o[e]); }
+      *reinterpret_cast<f32x4*>(out + col) = o;
+    }
+  }
+  (void)CPLX;
+  if (out && fp.amax_out) wire_amax_publish(fp.amax_out + (size_t)fp.L * WIRE_AMAX_SLOTS, amx, c.lane);
 }
 
 // final linear layer on h_L = act(accumulators of layer L): y[o] = sum_c h_L[c] wf[o][c] + bf[o]
@@ -460,7 +600,7 @@ constexpr int fx_lds_bytes() {
   return RING * NB * 2048 + (4 * 16 * NB + 16 * NB + FX_LMAX * 16 * NB + 4 * 16 * NB) * 4;   // (first layer sized for PF = P)
 }
 
-template <int KIND, int NB, int RING, int ABL = 0>
+template <int KIND, int NB, int RING, int ABL = 0, bool TRAIN = false>
 __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwdParams fp) {
   constexpr bool CPLX = FxKind<KIND>::CPLX;
   constexpr int P = 16 * NB, PF = CPLX ? P / 2 : P, S = NB / 2, STAGE = NB * 2048;
@@ -481,6 +621,7 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwd
   c.sW0 = sW0; c.sb0 = sb0; c.sbias = sbias; c.swf = swf;
   c.t = 0; c.T = fp.L * S; c.buf = 0;
   c.inv_prev = 1.f;
+  c.st_lin = nullptr; c.st_out = nullptr; c.st_split = false; c.st_inv_c = 1.f; c.amx = 0.f; c.ys = 0;
   // the weight stream starts first: it does not depend on anything below
   fx_issue<NB, RING>(fp, c, 0, 0);
   if (RING == 3 && c.T > 1) fx_issue<NB, RING>(fp, c, 1, 1);
@@ -498,23 +639,27 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwd
     const int l = i / P;
     sbias[i] = fp.c_hidden * fp.bias[(size_t)l * fp.bias_stride + (i - l * P)];
   }
-  for (int i = tid; i < fp.O * P; i += 64 * FX_WAVES) swf[i] = fp.wf[i];
+  if constexpr (!TRAIN) {                                // (the training forward ends at lin_L: no final layer here)
+    for (int i = tid; i < fp.O * P; i += 64 * FX_WAVES) swf[i] = fp.wf[i];
+  }
   __syncthreads();
 
   f32x4 accA[NB], accB[NB];
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb) accB[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  fx_layer<KIND, NB, RING, true, ABL>(fp, c, accB, accA, 1);
+  fx_layer<KIND, NB, RING, true, ABL, TRAIN>(fp, c, accB, accA, 1);
   int l = 2;
   for (; l + 1 <= fp.L; l += 2) {
-    fx_layer<KIND, NB, RING, false, ABL>(fp, c, accA, accB, l);
-    fx_layer<KIND, NB, RING, false, ABL>(fp, c, accB, accA, l + 1);
+    fx_layer<KIND, NB, RING, false, ABL, TRAIN>(fp, c, accA, accB, l);
+    fx_layer<KIND, NB, RING, false, ABL, TRAIN>(fp, c, accB, accA, l + 1);
   }
   if (l <= fp.L) {
-    fx_layer<KIND, NB, RING, false, ABL>(fp, c, accA, accB, l);
-    fx_final<KIND, NB>(fp, c, accB);
+    fx_layer<KIND, NB, RING, false, ABL, TRAIN>(fp, c, accA, accB, l);
+    if constexpr (TRAIN) fx_tail_train<KIND, NB>(fp, c, accB);
+    else fx_final<KIND, NB>(fp, c, accB);
   } else {
-    fx_final<KIND, NB>(fp, c, accA);
+    if constexpr (TRAIN) fx_tail_train<KIND, NB>(fp, c, accA);
+    else fx_final<KIND, NB>(fp, c, accA);
   }
 }
 
@@ -530,12 +675,17 @@ static std::atomic<int> g_fused_fwd{fx_env("WIRE_FUSED_FWD", 1)};
 #ifdef WIRE_FX_ABLATE
 static std::atomic<int> g_fx_ablate{0};
 #endif
+// "fused_train" / WIRE_FUSED_TRAIN: 1 (default) = training forwards of those nets run it too (storing lin_l / out_l)
+static std::atomic<int> g_fused_train{fx_env("WIRE_FUSED_TRAIN", 1)};
+bool fused_train_enabled() { return g_fused_train != 0 && g_fused_fwd != 0; }
 int fused_tune_get(const char* key) {
   if (!strcmp(key, "fused_fwd")) return g_fused_fwd;
+  if (!strcmp(key, "fused_train")) return g_fused_train;
   return -1;
 }
 int fused_tune_set(const char* key, int value) {
   if (!strcmp(key, "fused_fwd") && value >= 0 && value <= 1) { g_fused_fwd = value; return 0; }
+  if (!strcmp(key, "fused_train") && value >= 0 && value <= 1) { g_fused_train = value; return 0; }
 #ifdef WIRE_FX_ABLATE
   if (!strcmp(key, "fx_ablate") && value >= 0 && value <= 15) { g_fx_ablate = value; return 0; }
 #endif
@@ -560,10 +710,21 @@ template <int KIND, int NB, int RING, int ABL = 0>
 static hipError_t fx_launch_t(hipStream_t s, const FusedFwdParams& fp) {
   constexpr int LDS = fx_lds_bytes<NB, RING>();
   static_assert(LDS <= 160 * 1024, "LDS budget of a CU");
+  const unsigned grid = (unsigned)((fp.n + FX_ROWS - 1) / FX_ROWS);
+  if (fp.out != nullptr) {                               // training forward: stores what the backward reads
+    if constexpr (ABL == 0) {
+      const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_kernel<KIND, NB, RING, 0, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (attr != hipSuccess) return attr;
+      hipLaunchKernelGGL((fused_fwd_kernel<KIND, NB, RING, 0, true>), dim3(grid), dim3(64 * FX_WAVES), LDS, s, fp);
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_kernel<KIND, NB, RING, ABL>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (attr != hipSuccess) return attr;
-  const unsigned grid = (unsigned)((fp.n + FX_ROWS - 1) / FX_ROWS);
   hipLaunchKernelGGL((fused_fwd_kernel<KIND, NB, RING, ABL>), dim3(grid), dim3(64 * FX_WAVES), LDS, s, fp);
   return hipGetLastError();
 }
@@ -574,6 +735,8 @@ hipError_t launch_fused_fwd(hipStream_t s, int kind, int P, const FusedFwdParams
       fp.n > 0x7fffffffLL * FX_ROWS)
     return hipErrorInvalidValue;
   if (!(fp.c_first > 0.f) || !(fp.c_hidden > 0.f)) return hipErrorInvalidValue;
+  if (fp.out != nullptr && ((kind != NK_RELU && !fp.lin) || ((kind == NK_SIREN || kind == NK_GAUSS) && !fp.lin0) || !fp.amax_out))
+    return hipErrorInvalidValue;
 #ifdef WIRE_FX_ABLATE
   if (kind == NK_SIREN) {
     switch (g_fx_ablate.load()) {

@@ -155,7 +155,16 @@ struct FusedFwdParams {
   // (Gaussian), 1 (relu) -- c_first for layer 0 (first omega_0; applied to W0, b0 on the fly), c_hidden in the hidden
   // layers' images and biases; Gabor envelope: k2 = scale_0^2 log2 e / c^2
   float c_first = 1.f, c_hidden = 1.f, k2_first = 0.f, k2 = 0.f;
+  // training forward (out != null): what the backward reads is stored on the way -- rows of P floats, buffers padded to a
+  // multiple of 128 rows (every store is unconditional)
+  float* lin0 = nullptr;                                  // lin_0 [n][P] (sine, Gaussian)
+  float* lin = nullptr; long long lin_stride = 0;         // lin_l, l = 1 .. L, at lin + (l - 1) * lin_stride (not relu)
+  float* out = nullptr; long long out_stride = 0;         // out_l at out + l * out_stride: l = 0 fp32; 1 .. L - 1 pre-split
+                                                          // pairs at scale 1 (relu: fp32, and out_L too)
+  unsigned* amax_out = nullptr;                           // max |out_l| slots at amax_out + l * WIRE_AMAX_SLOTS (fp32-stored layers)
+  float inv_c_first = 1.f, inv_c_hidden = 1.f;            // 1 / c: lin is stored in the reference's units
 };
+bool fused_train_enabled();
 float fused_pre_scale(int kind, float omega0, float scale0);   // the c of a layer with these hyper-parameters
 bool fused_fwd_shape(int kind, int P);
 bool fused_fwd_enabled();
