@@ -5,7 +5,7 @@ mkdir -p build
 make -C wire_amd/csrc -j8 >/dev/null
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -c tools/wire_gemmx3g.hip -o build/wire_gemmx3g.o
 # the 2 x fp16 kernels once more with the tiled-A addressing probe compiled in (harness only)
-hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -DWIRE_X2_TILED_PROBE -DWIRE_X2_EXPERIMENTS -c wire_amd/csrc/wire_gemmx2h.hip -o build/wire_gemmx2h_probe.o
+hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -DWIRE_X2_TILED_PROBE -DWIRE_X2_EXPERIMENTS -c tools/wire_gemmx2h_probe.hip -o build/wire_gemmx2h_probe.o
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -c tools/gemm_x2_tune.hip -o build/gemm_x2_tune.o
 hipcc --offload-arch=gfx950 build/gemm_x2_tune.o build/csrc/wire_gemm.o build/csrc/wire_gemm3m.o build/csrc/wire_gemmx3.o \
       build/wire_gemmx3g.o build/csrc/wire_gemmx3h.o build/wire_gemmx2h_probe.o -o build/gemm_x2_tune

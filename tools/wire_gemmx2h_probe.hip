@@ -1,3 +1,7 @@
+// tools/wire_gemmx2h_probe.hip -- HARNESS EDITION of wire_amd/csrc/wire_gemmx2h.hip (state of round 4) with the timing-probe
+// branches of round 3 compiled in under WIRE_X2_TILED_PROBE / WIRE_X2_EXPERIMENTS ("results wrong" probes: stagger codes 777 - 785,
+// the 128-row / two-stage-prefetch / weight-ring editions).  Built only by tools/build_x2_tune.sh; the product file carries none
+// of these branches any more.
 // wire_gemmx2h.hip -- the layer GEMMs of the WIRE hot path as a TWO-way fp16 split on v_mfma_f32_16x16x32_f16.
 //
 // Arithmetic.  Every fp32 operand x is scaled by a power of two s (exact) and split into two fp16 terms,
@@ -23,13 +27,11 @@
 //  * 256 x 128 tile, 4 waves stacked in M (64 rows x 128 columns each), stages of 32 reduction indices: one MFMA
 //    covers the 32 k of a stage for ONE partial product -- three 16-cycle instructions per 16 x 16 block and stage,
 //    against six (as three paired ones per 16 k) in wire_gemmx3h.hip;
-//  * A (AMODE 2, default): the wave's 64 rows x 128 bytes of a stage go by LDS-DMA into a WAVE-PRIVATE, single-buffered
-//    8 KB region in WHOLE cache lines (an instruction fetches 8 rows x 128 B; the bank swizzle sits on the source address),
-//    which the wave reads into registers at the top of a stage and refills right away -- no barrier, no second buffer -- and
-//    splits in registers: 24 vector ops per 16-row block and stage (v_cvt_pk_f16_f32, v_fma_mix_f32), every lane productive --
-//    96 per wave and 32 k where the 3 x bf16 kernel spends 224.  (AMODE 1: every lane loads ITS fragment -- row lane & 15, k
-//    slot lane >> 4 -- straight from global memory into registers one stage ahead; AMODE 0: half-line LDS-DMA pieces: the
-//    editions of the first half of round 3, 6 % slower per step: twice the line requests on the vector-memory path.)
+//  * A: every lane loads ITS fragment of the wave's 64 rows (row lane & 15, k slot lane >> 4: 32 bytes per 16-row block)
+//    straight from global memory into registers, one stage ahead (AMODE 1, default; AMODE 0: the same rows by LDS-DMA into a
+//    WAVE-PRIVATE, single-buffered 8 KB region that the wave reads at the top of a stage and refills right away -- no
+//    barrier, no second buffer; 3 % slower), and splits it in registers: 24 vector ops per 16-row block and stage
+//    (v_cvt_pk_f16_f32, v_fma_mix_f32), every lane productive -- 96 per wave and 32 k where the 3 x bf16 kernel spends 224;
 //  * B: the pre-split weight image (x2_split_b_kernel), two 8 KB planes per stage, double-buffered by LDS-DMA; the
 //    image is stored in FRAGMENT order [16-column block][k slot][column][8 k], so a fragment read is lane * 16 bytes
 //    (conflict-free, one address register) and a DMA piece is 1 KB as it lies;
@@ -42,9 +44,9 @@
 #include <atomic>
 #include <cstring>
 
-#include "wire_dev.h"
-#include "wire_gemm.h"
-#include "wire_gemmh_epi.h"
+#include "../wire_amd/csrc/wire_dev.h"
+#include "../wire_amd/csrc/wire_gemm.h"
+#include "../wire_amd/csrc/wire_gemmh_epi.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -194,9 +196,23 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
       int row = m_base + wave * (16 * NRB) + rb * 16 + r;
       row = row < M ? row : M - 1;
       a_off[rb] = (unsigned)(row - m_base) * (unsigned)lda * 4u + (unsigned)(ksl * 32 + hq * 16);
+#ifdef WIRE_X2_TILED_PROBE
+      // timing probe (results wrong; AMODE 0): 785 -> a DMA instruction fetches 8 rows x 128 bytes (whole cache lines, each
+      // touched by ONE instruction) instead of 16 rows x 64 bytes (half lines, each line touched by two)
+      if (ep.stagger == 785) {
+        int row8 = m_base + wave * (16 * NRB) + rb * 16 + (lane >> 3);
+        row8 = row8 + 8 < M ? row8 : (M > 8 ? M - 9 : 0);     // (harness shapes only: the last tile has >= 9 rows)
+        row8 = row8 < m_base ? m_base : row8;
+        a_off[rb] = (unsigned)(row8 - m_base) * (unsigned)lda * 4u + (unsigned)((lane & 7) * 16);
+      }
+#endif
     }
   }
+#ifdef WIRE_X2_TILED_PROBE
+  const unsigned a_second = ep.stagger == 785 ? 8u * (unsigned)lda * 4u : 64u;
+#else
   constexpr unsigned a_second = 64u;
+#endif
   // AMODE 2: the same wave-private region filled in WHOLE CACHE LINES -- a DMA instruction fetches 8 rows x 128 bytes (lane =
   // (row l >> 3, 16-byte chunk), each line touched by exactly one instruction) instead of 16 rows x 64 bytes (each line
   // touched by two): half the line requests on the vector-memory path for the same bytes (profiles/r03_gemm_x2_whole_line.txt:
@@ -218,7 +234,13 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
         a_off2[rb][j] = (unsigned)(row - m_base) * (unsigned)lda * 4u + (unsigned)((pp ^ sw) * 16);
       }
   }
+#ifdef WIRE_X2_TILED_PROBE
+  // timing probe (results wrong): 784 -> every workgroup reads the rows of tile 0 -- the real access pattern (16 lines per
+  // load instruction, every lane its own row), served by the L2 instead of HBM
+  const char* const a_tile = reinterpret_cast<const char*>(A + (ep.stagger == 784 ? (size_t)0 : (size_t)m_base * lda));
+#else
   const char* const a_tile = reinterpret_cast<const char*>(A + (size_t)m_base * lda);
+#endif
   // B: the 16 KB of a stage lie in the image as they do in LDS: piece q = wave + 4 j, 1 KB each
   const char* const b_tile = reinterpret_cast<const char*>(Bx2) + (size_t)ct * nk * X2_BSTAGE;
   const unsigned b_off = (unsigned)(wave * 1024 + lane * 16);
@@ -232,9 +254,18 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
       int row = m_base + wave * (16 * NRB) + rb * 16 + r;
       row = row < M ? row : M - 1;
       g_off[rb] = (unsigned)(row - m_base) * (unsigned)lda * 4u + (unsigned)(ks * 32);
+#ifdef WIRE_X2_TILED_PROBE
+      // timing probe (results wrong): address A as if it were stored k-slab-major inside a 256-row tile --
+      // [stage][row][32 k] -- so that a workgroup stage reads one contiguous 32 KB block
+      if (ep.stagger == 777) g_off[rb] = (unsigned)(row - m_base) * 128u + (unsigned)(ks * 32);
+#endif
     }
   }
+#ifdef WIRE_X2_TILED_PROBE
+  const size_t a_step = ep.stagger == 777 ? (size_t)TBM * 128 : (size_t)(X2_BK * 4);
+#else
   constexpr size_t a_step = X2_BK * 4;
+#endif
   f32x4 araw[NRB][2];
   auto aload = [&](int kt) {
     const char* ab = a_tile + (size_t)kt * a_step;
@@ -358,6 +389,9 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
   __builtin_amdgcn_s_barrier();
 
   int buf = 0;
+#ifdef WIRE_X2_TILED_PROBE
+  f32x4 adummy = {0.f, 0.f, 0.f, 0.f};
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     if constexpr (AMODE == 0 || AMODE == 2) {
 #pragma unroll
@@ -377,6 +411,17 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
       __builtin_amdgcn_sched_barrier(0);
     }
     f16x8 ah[NRB], al[NRB];
+#ifdef WIRE_X2_TILED_PROBE
+    // timing probe (results wrong): the 32 bytes a lane loads per block taken AS the two fp16 fragments -- what the loop
+    // costs when the producer has stored the activation already split (no vector ops between the loads and the MFMAs)
+    if (ep.stagger == 778) {
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+        ah[rb] = __builtin_bit_cast(f16x8, araw[rb][0]);
+        al[rb] = __builtin_bit_cast(f16x8, araw[rb][1]);
+      }
+    } else
+#endif
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) {
       if constexpr (APRE) {
@@ -397,6 +442,35 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
     if constexpr (AMODE == 1) {
       // the raw registers are free again: next stage's rows and weight pieces go out under this stage's MFMAs
       __builtin_amdgcn_sched_barrier(0);
+#ifdef WIRE_X2_TILED_PROBE
+      // timing probe (results wrong): the rows of the next stage are loaded as always but into registers nothing waits
+      // for before the end of the loop -- every stage computes on the rows of stage 0: the loop with its memory traffic
+      // and without its dependence on it
+      if (ep.stagger == 782) {
+        if (kt + 1 < nk) {
+          issue(kt + 1, buf ^ 1);
+          // (by LDS-DMA into the wave's idle 8 KB: no register is the target of a load nobody waits for)
+          const char* ab = a_tile + (size_t)(kt + 1) * a_step;
+          if constexpr (NRB == 4) {
+            if (ep.kvalid == -783) {
+              // ... or into ONE register quad that stays live ("+v": the allocator must not hand it to anything else while
+              // loads are in flight into it); in-order returns make the overwrites harmless
+#pragma unroll
+              for (int rb = 0; rb < NRB; ++rb) {
+                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(adummy) : "v"(ab + g_off[rb]) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(adummy) : "v"(ab + g_off[rb] + 16) : "memory");
+              }
+            } else {
+#pragma unroll
+              for (int rb = 0; rb < NRB; ++rb) {
+                x2_dma16(ab + g_off[rb], a_lds + rb * 2048);
+                x2_dma16(ab + g_off[rb] + 16, a_lds + rb * 2048 + 1024);
+              }
+            }
+          }
+        }
+      } else
+#endif
       if constexpr (BRING) {
         // rows of the next stage first, then the weight pieces of the one after: the stage-end wait leaves those 4 in flight
         if (kt + 1 < nk) aload(kt + 1);
@@ -428,6 +502,14 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef WIRE_X2_TILED_PROBE
+    // timing probes (results wrong): 779 no wait for the stage's loads, 780 no workgroup barrier, 781 neither
+    if (ep.stagger == 782) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); __builtin_amdgcn_s_barrier(); }   // the weight pieces only
+    else if (ep.stagger == 779) { __builtin_amdgcn_s_barrier(); }
+    else if (ep.stagger == 780) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    else if (ep.stagger == 781) { }
+    else
+#endif
     {
     if (BRING && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -436,6 +518,14 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (BRING) buf = buf == 2 ? 0 : buf + 1; else buf ^= 1;
   }
+#ifdef WIRE_X2_TILED_PROBE
+  if (ep.stagger == 782) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(adummy));
+    if (adummy[0] == 123.456f) acc[0][0][0] += adummy[1];
+    __builtin_amdgcn_s_barrier();           // (the epilogues reuse this LDS)
+  }
+#endif
   h_epilogue<EPI, true, NRB>(acc, ep, M, m_base + wave * (16 * NRB), n_base, Nc, lane, smem, wave, rt, inv_a * inv_b);
 }
 
@@ -452,6 +542,9 @@ static int x2_env(const char* name, int dflt) {
 // half-line pieces of AMODE 0 and the fragment-shaped register loads of AMODE 1 (16 rows x 64 bytes per instruction) put
 // twice the line requests on the vector-memory path for the same bytes (profiles/r03_gemm_x2_whole_line.txt).
 static std::atomic<int> g_x2_amode{x2_env("WIRE_X2_AMODE", 2)};
+// 128-row tiles (3 workgroups per CU) for every epilogue but the first-layer data gradients, whose per-tile sums are laid
+// out for 256-row tiles.  "x2_rows128" / WIRE_X2_ROWS128.
+static std::atomic<int> g_x2_rows128{x2_env("WIRE_X2_ROWS128", 0)};
 // "x2_tn_rows" / WIRE_X2_TN_ROWS: upper bound on the rows ONE weight-gradient workgroup accumulates sequentially in its fp32
 // accumulators (0 = the fill-the-chip policy of gemmx2_tn_splits alone).  A shorter chain means more row splits, i.e.
 // more slabs for wgrad_reduce_kernel: the knob of the summation-order measurement (tools/wgrad_order_probe.py).
@@ -464,6 +557,7 @@ int gemmx2h_tune_get(const char* key) {
 int gemmx2h_tune_set(const char* key, int value) {
   if (!strcmp(key, "x2_amode") && value >= 0 && value <= 2) { g_x2_amode = value; return 0; }
   if (!strcmp(key, "x2_tn_rows") && value >= 0 && (value == 0 || value >= 256)) { g_x2_tn_rows = value; return 0; }
+  if (!strcmp(key, "x2_rows128") && value >= 0 && value <= 3) { g_x2_rows128 = value; return 0; }
   return -1;
 }
 
@@ -471,13 +565,35 @@ int gemmx2h_tune_set(const char* key, int value) {
 template <int EPI>
 static hipError_t launchx2h_t(hipStream_t s, const float* A, int lda, const unsigned short* Bx2, int64_t M, int Nc,
                               int Kd, const GemmEpiParams& ep) {
-  // (128-row tiles at three workgroups per CU, two stages of prefetch, a ring of three weight stages: bit-identical and measured
-  //  no faster -- profiles/r03_gemm_x2_rows128.txt, r03_gemm_x2_prefetch2.txt; they live on in tools/wire_gemmx2h_probe.hip)
-  const int tbm = X2_TBM;
+  // the 128-row editions (three workgroups per CU; optionally two stages of prefetch) are bit-identical and measured no
+  // faster (profiles/r03_gemm_x2_rows128.txt, r03_gemm_x2_prefetch2.txt): they are compiled into the harness build only
+#ifdef WIRE_X2_EXPERIMENTS
+  const bool small = g_x2_rows128 != 0 && g_x2_rows128 != 3 && EPI != EPI_GABOR_BWD_FIRST && EPI != EPI_GABOR2D_BWD_FIRST && !ep.cr_partial &&
+                     ep.a_split_inv == 0.f;
+#else
+  const bool small = false;
+#endif
+  const int tbm = small ? 128 : X2_TBM;
   const int tiles_m = (int)((M + tbm - 1) / tbm);
   const int tiles_n = (Nc + X2_TBN - 1) / X2_TBN;
   const int tiles_m_pad = (tiles_m + 7) & ~7;
   const dim3 grid((unsigned)(tiles_m_pad * tiles_n));
+#ifdef WIRE_X2_EXPERIMENTS
+  if constexpr (EPI != EPI_GABOR_BWD_FIRST && EPI != EPI_GABOR2D_BWD_FIRST) {
+    if (small && g_x2_rows128 == 2 && (Kd & 63) == 0) {   // two stages of prefetch
+      hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 1, 2, 2>), grid, dim3(256), 0, s, A, lda, Bx2, (int)M, Nc, Kd, tiles_m, tiles_n, ep);
+      return hipGetLastError();
+    }
+    if (small) {
+      hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 1, 2>), grid, dim3(256), 0, s, A, lda, Bx2, (int)M, Nc, Kd, tiles_m, tiles_n, ep);
+      return hipGetLastError();
+    }
+  }
+  if (g_x2_rows128 == 3 && ep.a_split_inv == 0.f) {       // weight ring of three stages on the default tile
+    hipLaunchKernelGGL((gemmx2h_nt_kernel<EPI, 1, 4, 3>), grid, dim3(256), 0, s, A, lda, Bx2, (int)M, Nc, Kd, tiles_m, tiles_n, ep);
+    return hipGetLastError();
+  }
+#endif
   if (ep.a_split_inv != 0.f) {
     // (only the forward forms read an activation; the data gradients read g_lin, which has no a-priori bound)
     if constexpr (EPI == EPI_STORE || EPI == EPI_GABOR_FWD || EPI == EPI_GABOR2D_FWD || EPI == EPI_SIREN_FWD ||

@@ -350,7 +350,7 @@ float fused_act_scale(const Plan& p);
 bool fused_train_applies(const Plan& p, int64_t n) {
   if (!fused_train_enabled() || p.off_fx < 0 || p.L < 1 || p.L > 8 || p.first_gemm) return false;
   if (!use_x2(p, n) || !gemmx2_tn_applies(p.Pl, p.P) || !g_split_out || !g_recompute_out) return false;
-  if (p.kind == WIRE_KIND_WIRE && p.P > 256) return false;
+  if (p.kind == WIRE_KIND_WIRE && p.P > 256 && env_int_("WIRE_FUSED_TRAIN_P384", 0) == 0) return false;
   if (p.kind != WIRE_KIND_RELU && fused_act_scale(p) == 0.f) return false;
   return fused_pre_scale(p.kind, p.w1, p.s) > 0.f && fused_pre_scale(p.kind, p.w, p.s) > 0.f;
 }

@@ -472,13 +472,20 @@ WIRE_DEVINL void fx_layer(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)
   (void)sB;
   fx_u32x4 Fh[S], Fl[S];
   f32x4 w[4];
-  // parts 0 and 1 (what stage 0 -- wire: stages 0 and 1 -- consumes) before the first stage
+  // parts 0 and 1 (what stage 0 -- wire: stages 0 and 1 -- consumes) before the first stage.  (PIPE = false -- ALL parts
+  // before the first stage, the stages carrying MFMAs and fragment reads only -- was tried for P = 384, whose two accumulator
+  // sets of 96 registers leave the pipelined producer 92 (forward-only) to 305 (training) spilled registers: it spilled
+  // 324 / 604 instead and stays off.  The P = 384 training forward is therefore not dispatched: with its spills it ran the
+  // K = 181 step 10 % SLOWER than the layer-by-layer kernels, 4.85 against 4.39 ms on one box.)
   // ys[0] / ys[1]: stores issued since the last / the last but one weight-stream issue (the counted wait of fx_stage_top)
+  constexpr bool PIPE = true;
   int ys0 = c.ys, ys1 = 0;
 #pragma unroll
-  for (int jj = (CPLX ? -2 : -1); jj < 0; ++jj)
+  for (int jj = (CPLX ? -2 : -1); jj < (PIPE ? 0 : S); ++jj) {
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) ys0 += fx_slice<KIND, NB, FROM_COORDS, TRAIN>(fp, c, src, l - 1, sA, jj, cb, w, Fh, Fl);
+    if constexpr (!PIPE) __builtin_amdgcn_sched_barrier(0);   // one part at a time: the scheduler must not open them all
+  }
 #pragma unroll
   for (int j = 0; j < S; ++j) {
     // RING 3: the pieces of stage t were issued two tops ago -- younger: the stores since then (ys1 + ys0) and the pieces of
@@ -507,7 +514,7 @@ WIRE_DEVINL void fx_layer(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)
       else FX_MFMA(xl, ah, dst[cb]);
       FX_MFMA(xh, al, dst[cb]);
       FX_MFMA(xh, ah, dst[cb]);
-      if constexpr (!(ABL & 1)) ys0 += fx_slice<KIND, NB, FROM_COORDS, TRAIN>(fp, c, src, l - 1, sA, j, cb, w, Fh, Fl);
+      if constexpr (!(ABL & 1) && PIPE) ys0 += fx_slice<KIND, NB, FROM_COORDS, TRAIN>(fp, c, src, l - 1, sA, j, cb, w, Fh, Fl);
       __builtin_amdgcn_sched_barrier(0);
     }
     c.t += 1;

@@ -9,8 +9,11 @@ API parity (reference file:line):
       .forward(coords) -> real [..., out]         modules/wire.py:161-167
 state_dict keys, dtypes (complex64 parameters) and default-init RNG order are
 the reference's, so checkpoints move both ways.  The arithmetic is not PyTorch:
-forward and backward run in libwire_hip.so (fp32-MFMA GEMM + fused Gabor
-epilogues); there is no CPU path.
+forward and backward run in libwire_hip.so -- by default the hidden-layer GEMMs as
+a 2 x fp16 split on the f16 matrix cores with fp32 accumulation and fused Gabor
+epilogues (wire_gemmx2h.hip; forward-only calls of the narrower nets as ONE kernel,
+wire_fused.hip), selectable: 3 x bf16 split, exact-fp32 MFMA; there
+is no CPU path.
 """
 from __future__ import annotations
 
