@@ -175,6 +175,7 @@ struct Plan {
   std::vector<int64_t> off_fwd, off_dg, off_bias, off_fwd_x3, off_dg_x3, off_fwd_3m, off_dg_3m, off_fwd_x2, off_dg_x2;
   int64_t off_wf, off_bf, off_first, off_wamax, total_packed;   // off_wamax: max-|weight| slots, WIRE_AMAX_SLOTS per layer
   int64_t off_fx;    // k-permuted 2 x fp16 images of the hidden layers for the fused forward (wire_fused.hip), -1 = no such shape
+  int64_t off_fxd;   // the same of the TRANSPOSED weights of layers L .. 2 (in that order) for the data-gradient chain, -1 = none
   std::vector<int64_t> tfloats;
 };
 
@@ -243,6 +244,8 @@ int make_plan(const wire_net_desc* d, Plan& p) {
   p.off_wamax = off; off += (int64_t)(p.L + 1) * WIRE_AMAX_SLOTS;
   p.off_fx = -1;
   if (!p.first_gemm && p.L >= 1 && fused_fwd_shape(p.kind, p.P)) { p.off_fx = off; off += (int64_t)p.L * fused_b_image_floats(p.P); }
+  p.off_fxd = -1;
+  if (!p.first_gemm && p.L >= 2 && fused_bwd_shape(p.kind, p.P)) { p.off_fxd = off; off += (int64_t)(p.L - 1) * fused_b_image_floats(p.P); }
   p.off_wf = off; off += (int64_t)p.O * p.P;
   p.off_bf = off; off += 64;
   p.off_first = off;   // native copies of the first layer's tensors (W0,b0[,V0,c0])
@@ -283,13 +286,17 @@ ActLayout act_layout(const Plan& p, int64_t n, int save) {
   return a;
 }
 
-struct ScratchLayout { int64_t ga, gb, gu, slab, bslab, fpw, fpb, crp, gamax, total; int S; };
+struct ScratchLayout { int64_t ga, gb, gu, slab, bslab, fpw, fpb, crp, gamax, gch, gch_stride, total; int S; };
 ScratchLayout scratch_layout(const Plan& p, int64_t n) {
   ScratchLayout s{};
   int64_t off = 0;
   s.gamax = off; off += (int64_t)(p.L + 2) * WIRE_AMAX_SLOTS;   // max |g_lin_l| slots (2 x fp16 GEMMs)
   s.ga = off; off += n * p.Pl;
   s.gb = off; off += n * p.Pl;
+  // the data-gradient chain (wire_fused.hip: fused_bwd_kernel) keeps EVERY g_lin_l (l = 1 .. L; the weight-gradient GEMMs
+  // run after it), rows padded to 128: g_lin_l at gch + l * gch_stride
+  s.gch = -1; s.gch_stride = (n + 127) / 128 * 128 * p.Pl;
+  if (p.off_fxd >= 0) { s.gch = off; off += (int64_t)(p.L + 1) * s.gch_stride; }
   s.gu = off; if (p.cplx) off += n * p.ldu * (p.kind == WIRE_KIND_WIRE2D ? 2 : 1);
   const int64_t pn = p.first_gemm && p.Pin0 > p.P ? p.Pin0 : p.P;
   // slabs sized for the largest split count of the three GEMM families (flag-independent scratch size)
@@ -353,6 +360,11 @@ bool fused_train_applies(const Plan& p, int64_t n) {
   if (p.kind == WIRE_KIND_WIRE && p.P > 256 && env_int_("WIRE_FUSED_TRAIN_P384", 0) == 0) return false;
   if (p.kind != WIRE_KIND_RELU && fused_act_scale(p) == 0.f) return false;
   return fused_pre_scale(p.kind, p.w1, p.s) > 0.f && fused_pre_scale(p.kind, p.w, p.s) > 0.f;
+}
+// ... and its data gradients g_lin_L -> .. -> g_lin_1 as ONE kernel (the last link, layer 1 with the first layer's sums,
+// stays with the layer-by-layer kernel)
+bool fused_bwd_applies(const Plan& p, int64_t n) {
+  return fused_bwd_enabled() && p.off_fxd >= 0 && p.L >= 2 && fused_train_applies(p, n);
 }
 float out_split_scale(const Plan& p, int64_t n, int l) {
   if (!g_split_out || l < 1 || l >= p.L || p.kind == WIRE_KIND_RELU) return 0.f;
@@ -512,6 +524,19 @@ extern "C" int wire_pack_params(void* stream, const wire_net_desc* d, const void
           fx.slots[i] = ab.slots[i];
         }
         HIPCHK(launch_fx_split_b_batch(s, fx, nb, p.P, p.P, fused_pre_scale(p.kind, p.w, p.s)));
+      }
+      if (p.off_fxd >= 0) {                                // the data-gradient chain's: transposed images, layers L .. 2
+        FxSplitBatch fd{};
+        int m = 0;
+        for (int i = 0; i < nb; ++i) {
+          const int l = l0 + i;
+          if (l < 2) continue;
+          fd.src[m] = packed + p.off_dg[l];
+          fd.dst[m] = packed + p.off_fxd + (int64_t)(p.L - l) * fused_b_image_floats(p.P);
+          fd.slots[m] = ab.slots[i];
+          ++m;
+        }
+        if (m > 0) HIPCHK(launch_fx_split_b_batch(s, fd, m, p.Pl, p.P, 1.f));
       }
     }
   }
@@ -730,8 +755,25 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
                                             p.ldu));
   }
 
+  // ---- the data gradients of layers L .. 2 as one chain (wire_fused.hip): every g_lin_l lands in its own buffer, the
+  // weight-gradient GEMMs below read them, the layer-1 data gradient (first layer's sums) runs as before on g_lin_1
+  const bool chain = !do_final && fused_bwd_applies(p, n);
+  if (chain) {
+    FusedBwdParams bp;
+    bp.n = n;
+    bp.g = Sx + sc.gch; bp.g_stride = sc.gch_stride;
+    bp.gamax = gamax;
+    bp.aux = p.kind == WIRE_KIND_RELU ? A + a.out0 : A + a.lin1 - a.np * p.Pl;   // lin_l at lin1 + (l - 1) * np * Pl
+    bp.aux_stride = p.kind == WIRE_KIND_RELU ? a.np * p.P : a.np * p.Pl;
+    bp.wimg = reinterpret_cast<const unsigned char*>(packed + p.off_fxd);
+    bp.wamax = reinterpret_cast<const unsigned*>(packed + p.off_wamax) + WIRE_AMAX_SLOTS; bp.wamax_stride = WIRE_AMAX_SLOTS;
+    bp.L = p.L; bp.w = p.w; bp.s = p.s;
+    ProfScope ps(s, 1, 2.0 * n * p.Pl * p.P * (p.L - 1));
+    HIPCHK(launch_fused_bwd(s, p.kind, p.P, bp));
+  }
   // ---- hidden layers L..1
   for (int l = p.L; l >= 1; --l) {
+    if (chain) gcur = Sx + sc.gch + (int64_t)l * sc.gch_stride;
     float* gW = (float*)grads[p.per_layer * l];
     float* gb = (float*)grads[p.per_layer * l + 1];
     float* gV = p.per_layer == 4 ? (float*)grads[p.per_layer * l + 2] : nullptr;
@@ -790,6 +832,7 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
       if (p.per_layer == 4) { ep.W0b = packed + first_native_off(p, 2); ep.b0b = packed + first_native_off(p, 3); }
     }
     if (!p.cplx && l == 1) ep.ld0 = p.P;
+    if (chain && l >= 2) continue;                          // g_lin_{l-1} is already there
     { ProfScope ps(s, 1, 2.0 * n * p.Pl * p.P);
       if (x2) {
         ep.amax_a = gamax + l * WIRE_AMAX_SLOTS; ep.amax_b = wamax(l);
@@ -893,9 +936,10 @@ extern "C" int wire_train_fwd_bwd_hooked(void* stream, const wire_net_desc* d, c
     const bool x2 = use_x2(p, n);
     unsigned* const gamax = reinterpret_cast<unsigned*>(Sx + sc.gamax);
     if (x2) HIPCHK(hipMemsetAsync(gamax, 0, (size_t)(p.L + 2) * WIRE_AMAX_SLOTS * sizeof(unsigned), s));
+    float* gL = fused_bwd_applies(p, n) ? Sx + sc.gch + (int64_t)p.L * sc.gch_stride : Sx + sc.ga;
     HIPCHK(launch_final_fused(s, p.kind, recomp ? nullptr : A + a.out0 + (int64_t)p.L * a.np * p.P, linL, n, p.P, p.O,
                               p.K, packed + p.off_wf, packed + p.off_bf, target, idx, first, weight,
-                              p.w, p.s, y, rec, Sx + sc.ga, Sx + sc.fpw, Sx + sc.fpb, Sx + sc.crp, loss_out,
+                              p.w, p.s, y, rec, gL, Sx + sc.fpw, Sx + sc.fpb, Sx + sc.crp, loss_out,
                               x2 ? gamax + p.L * WIRE_AMAX_SLOTS : nullptr));
   }
   return mlp_bwd_core(stream, p, packed, coords, n, nullptr, act, act_bytes, scratch, scratch_bytes, grads, false, ready,

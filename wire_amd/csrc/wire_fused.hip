@@ -170,8 +170,8 @@ struct FxCtx {
   int ys;                     // vector-memory operations issued since the last weight-stream issue (stores: counted waits)
 };
 
-template <int NB, int RING>
-WIRE_DEVINL void fx_issue(const FusedFwdParams& fp, const FxCtx& c, int t, int buf) {
+template <int NB, int RING, typename PT>
+WIRE_DEVINL void fx_issue(const PT& fp, const FxCtx& c, int t, int buf) {
   constexpr int STAGE = NB * 2048, PIECES = NB / 4;
   const unsigned char* src = fp.wimg + (size_t)t * STAGE + c.wave * 1024 + c.lane * 16;
   unsigned char* dst = c.ring + buf * STAGE + c.wave * 1024;
@@ -197,8 +197,8 @@ WIRE_DEVINL void fx_wait_vm(const int n) {
 // `younger` = vector-memory operations that were CERTAINLY issued after the pieces of stage c.t (the training forward's
 // stores and, with RING = 3, the pieces of stage c.t + 1): the wait may leave exactly those in flight.  Never more than were
 // issued -- a count that is too high would let a piece of stage c.t stay in flight.
-template <int NB, int RING, int ABL>
-WIRE_DEVINL void fx_stage_top(const FusedFwdParams& fp, FxCtx& c, const int younger_stores) {
+template <int NB, int RING, int ABL, typename PT>
+WIRE_DEVINL void fx_stage_top(const PT& fp, FxCtx& c, const int younger_stores) {
   constexpr int PIECES = NB / 4;
   if constexpr (!(ABL & 4)) {
     if (RING == 3 && c.t + 1 < c.T) fx_wait_vm(PIECES + younger_stores);
@@ -671,6 +671,142 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwd
 }
 
 // ---------------------------------------------------------------------------
+// the data-gradient CHAIN of the real nets: g_lin_L -> g_lin_{L-1} -> ... -> g_lin_1 in one kernel
+//
+//   g_out_{l-1} = g_lin_l W_l          (the transposed weight image, same k-permuted 2 x fp16 format)
+//   g_lin_{l-1} = g_out_{l-1} * act'(lin_{l-1})        (autograd of modules/siren.py:48-49, gauss.py:27-28, relu.py:28-29)
+//
+// with g_lin_l never re-read: the accumulators of one link, multiplied by the activation derivative, ARE the next link's
+// activation operand (the same register chaining as the forward).  Each g_lin_{l-1} is stored once (the weight-gradient GEMM
+// of layer l - 1 reads it) with its maximum published for that GEMM's operand scale; lin_{l-1} (relu: out_{l-1}) is
+// prefetched into registers while the link's MFMAs run.  The scale of a link's operand is the wave's own maximum of the
+// g_lin it has just formed (gradients have no a-priori bound), so a link's epilogue is not pipelined under the next link's
+// MFMAs; the two waves of a SIMD overlap instead.  The last link (layer 1: the first layer's sums) stays with the
+// layer-by-layer kernel (wire_gemmh_epi.h, cr_partial).
+// ---------------------------------------------------------------------------
+template <int KIND, int NB, int RING>
+__global__ __launch_bounds__(64 * FX_WAVES) void fused_bwd_kernel(const FusedBwdParams fp) {
+  constexpr int ACT = FxKind<KIND>::ACT;
+  constexpr int P = 16 * NB, S = NB / 2, STAGE = NB * 2048;
+  static_assert(!FxKind<KIND>::CPLX, "real nets");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char fx_smem[];
+  const int tid = threadIdx.x;
+  FxCtx c;
+  c.lane = tid & 63;
+  c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  c.g = c.lane >> 4;
+  c.n = fp.n;
+  c.row = (long long)blockIdx.x * FX_ROWS + c.wave * 16 + (c.lane & 15);
+  c.ring = fx_smem;
+  const int links = fp.L - 1;                            // layers L .. 2
+  c.t = 0; c.T = links * S; c.buf = 0;
+  c.ys = 0;
+  fx_issue<NB, RING>(fp, c, 0, 0);
+  if (RING == 3 && c.T > 1) fx_issue<NB, RING>(fp, c, 1, 1);
+  const size_t ro = (size_t)c.row * P + 4 * c.g;         // this lane's first column of block 0 (rows are padded to 128)
+
+  // ---- the first operand: g_lin_L from memory, scaled by its tensor maximum (published by the final stage)
+  f32x4 acc[NB];
+  {
+    const float* gp = fp.g + (size_t)fp.L * fp.g_stride + ro;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) acc[cb] = *reinterpret_cast<const f32x4*>(gp + 16 * cb);
+  }
+  // rows beyond n (the last workgroup's overhang into the padding rows) carry zeros: whatever lies in the padding must
+  // reach neither the wave's scale nor the published maxima
+  const bool valid = c.row < c.n;
+  if (!valid) {
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float sA, invA;
+  wire_x2_scales(wire_amax_read(fp.gamax + (size_t)fp.L * WIRE_AMAX_SLOTS, c.lane), sA, invA);
+  fx_u32x4 Fh[S], Fl[S];
+  int ys0 = 0, ys1 = 0;
+  for (int l = fp.L; l >= 2; --l) {
+    // fragments of g_lin_l: blocks 2 j, 2 j + 1 of the lane's registers are stage j
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+      x2_split2(acc[2 * j][0], acc[2 * j][1], sA, h0, l0);
+      x2_split2(acc[2 * j][2], acc[2 * j][3], sA, h1, l1);
+      x2_split2(acc[2 * j + 1][0], acc[2 * j + 1][1], sA, h2, l2);
+      x2_split2(acc[2 * j + 1][2], acc[2 * j + 1][3], sA, h3, l3);
+      Fh[j] = fx_u32x4{h0, h1, h2, h3};
+      Fl[j] = fx_u32x4{l0, l1, l2, l3};
+    }
+    // lin_{l-1} (relu: out_{l-1}) of this lane's 64 columns: in flight under the MFMAs below
+    f32x4 aux[NB];
+    {
+      const float* ap = fp.aux + (size_t)(l - 1) * fp.aux_stride + ro;
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) aux[cb] = *reinterpret_cast<const f32x4*>(ap + 16 * cb);
+      ys0 += NB;
+    }
+    float sB, invB;
+    wire_x2_scales(wire_amax_read(fp.wamax + (size_t)(l - 1) * fp.wamax_stride, c.lane), sB, invB);
+    (void)sB;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      fx_stage_top<NB, RING, 0>(fp, c, RING == 3 ? ys1 + ys0 : ys0);
+      ys1 = ys0; ys0 = 0;
+      const unsigned char* Sb = c.ring + c.buf * STAGE + c.lane * 16;
+      const fx_f16x8 ah = __builtin_bit_cast(fx_f16x8, Fh[j]), al = __builtin_bit_cast(fx_f16x8, Fl[j]);
+      fx_f16x8 bh[FX_PFD + 1], bl[FX_PFD + 1];
+#pragma unroll
+      for (int cb = 0; cb < FX_PFD; ++cb) {
+        bh[cb] = *reinterpret_cast<const fx_f16x8*>(Sb + cb * 1024);
+        bl[cb] = *reinterpret_cast<const fx_f16x8*>(Sb + (NB + cb) * 1024);
+      }
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) {
+        if (cb + FX_PFD < NB) {
+          bh[(cb + FX_PFD) % (FX_PFD + 1)] = *reinterpret_cast<const fx_f16x8*>(Sb + (cb + FX_PFD) * 1024);
+          bl[(cb + FX_PFD) % (FX_PFD + 1)] = *reinterpret_cast<const fx_f16x8*>(Sb + (NB + cb + FX_PFD) * 1024);
+        }
+        const fx_f16x8 xh = bh[cb % (FX_PFD + 1)], xl = bl[cb % (FX_PFD + 1)];
+        if (j == 0) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, ah, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        else FX_MFMA(xl, ah, acc[cb]);
+        FX_MFMA(xh, al, acc[cb]);
+        FX_MFMA(xh, ah, acc[cb]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      c.t += 1;
+      c.buf = c.buf + 1 == RING ? 0 : c.buf + 1;
+    }
+    // ---- epilogue of the link: g_lin_{l-1} = g_out * act'(lin_{l-1}), stored, its maximum tracked
+    const float inv = invA * invB;
+    float amx = 0.f;
+    float* gp = fp.g + (size_t)(l - 1) * fp.g_stride + ro;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      f32x4 gl;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float go = acc[cb][e] * inv;
+        float out = 0.f;
+        if (ACT == ACT_GAUSS) out = real_act_fwd_lean<ACT_GAUSS>(aux[cb][e], fp.w, fp.s);
+        if (ACT == ACT_RELU) out = aux[cb][e];
+        gl[e] = valid ? real_act_bwd_lean<ACT>(go, aux[cb][e], out, fp.w, fp.s) : 0.f;
+        amx = __builtin_fmaxf(amx, __builtin_fabsf(gl[e]));
+      }
+      *reinterpret_cast<f32x4*>(gp + 16 * cb) = gl;
+      acc[cb] = gl;
+    }
+    ys0 += NB;
+    // the next link's operand scale from this wave's maximum; the tensor's maximum for the weight-gradient GEMM
+#pragma unroll
+    for (int o = 32; o; o >>= 1) amx = __builtin_fmaxf(amx, __shfl_xor(amx, o));
+    wire_x2_scales((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(amx)), sA, invA);
+    if (c.lane == 0) {
+      const unsigned bits = __float_as_uint(amx);
+      unsigned* slot = fp.gamax + (size_t)(l - 1) * WIRE_AMAX_SLOTS + (blockIdx.x & (WIRE_AMAX_SLOTS - 1));
+      if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 static int fx_env(const char* name, int dflt) {
@@ -685,14 +821,18 @@ static std::atomic<int> g_fx_ablate{0};
 // "fused_train" / WIRE_FUSED_TRAIN: 1 (default) = training forwards of those nets run it too (storing lin_l / out_l)
 static std::atomic<int> g_fused_train{fx_env("WIRE_FUSED_TRAIN", 1)};
 bool fused_train_enabled() { return g_fused_train != 0 && g_fused_fwd != 0; }
+int fused_bwd_knob();
+void fused_bwd_knob_set(int v);
 int fused_tune_get(const char* key) {
   if (!strcmp(key, "fused_fwd")) return g_fused_fwd;
   if (!strcmp(key, "fused_train")) return g_fused_train;
+  if (!strcmp(key, "fused_bwd")) return fused_bwd_knob();
   return -1;
 }
 int fused_tune_set(const char* key, int value) {
   if (!strcmp(key, "fused_fwd") && value >= 0 && value <= 1) { g_fused_fwd = value; return 0; }
   if (!strcmp(key, "fused_train") && value >= 0 && value <= 1) { g_fused_train = value; return 0; }
+  if (!strcmp(key, "fused_bwd") && value >= 0 && value <= 1) { fused_bwd_knob_set(value); return 0; }
 #ifdef WIRE_FX_ABLATE
   if (!strcmp(key, "fx_ablate") && value >= 0 && value <= 15) { g_fx_ablate = value; return 0; }
 #endif
@@ -773,3 +913,31 @@ hipError_t launch_fused_fwd(hipStream_t s, int kind, int P, const FusedFwdParams
 #ifdef FX_PROBE_ABL
 template __global__ void fused_fwd_kernel<NK_SIREN, 16, 3, FX_PROBE_ABL>(const FusedFwdParams);
 #endif
+
+// ---- the data-gradient chain (real nets, P = 256)
+static std::atomic<int> g_fused_bwd{fx_env("WIRE_FUSED_BWD", 1)};
+bool fused_bwd_enabled() { return g_fused_bwd != 0 && fused_train_enabled(); }
+bool fused_bwd_shape(int kind, int P) { return (kind == NK_SIREN || kind == NK_GAUSS || kind == NK_RELU) && P == 256; }
+template <int KIND>
+static hipError_t fxb_launch_t(hipStream_t s, const FusedBwdParams& fp) {
+  constexpr int NB = 16, RING = 3, LDS = RING * NB * 2048;
+  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_bwd_kernel<KIND, NB, RING>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  if (attr != hipSuccess) return attr;
+  const unsigned grid = (unsigned)((fp.n + FX_ROWS - 1) / FX_ROWS);
+  hipLaunchKernelGGL((fused_bwd_kernel<KIND, NB, RING>), dim3(grid), dim3(64 * FX_WAVES), LDS, s, fp);
+  return hipGetLastError();
+}
+hipError_t launch_fused_bwd(hipStream_t s, int kind, int P, const FusedBwdParams& fp) {
+  if (fp.n <= 0 || fp.L < 2) return hipSuccess;
+  if (!fused_bwd_shape(kind, P) || fp.L > FX_LMAX || !fp.g || !fp.aux || !fp.gamax || !fp.wamax || !fp.wimg)
+    return hipErrorInvalidValue;
+  switch (kind) {
+    case NK_SIREN: return fxb_launch_t<NK_SIREN>(s, fp);
+    case NK_GAUSS: return fxb_launch_t<NK_GAUSS>(s, fp);
+    case NK_RELU: return fxb_launch_t<NK_RELU>(s, fp);
+    default: return hipErrorInvalidValue;
+  }
+}
+int fused_bwd_knob() { return g_fused_bwd; }
+void fused_bwd_knob_set(int v) { g_fused_bwd = v; }

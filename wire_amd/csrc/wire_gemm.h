@@ -171,3 +171,19 @@ bool fused_fwd_enabled();
 int fused_tune_get(const char* key);                      // "fused_fwd"; -1 = unknown key
 int fused_tune_set(const char* key, int value);
 hipError_t launch_fused_fwd(hipStream_t s, int kind, int P, const FusedFwdParams& fp);
+
+// ---- the data-gradient chain of the real nets in one kernel (wire_fused.hip: fused_bwd_kernel): g_lin_L .. g_lin_1
+struct FusedBwdParams {
+  long long n = 0;
+  float* g = nullptr; long long g_stride = 0;             // g_lin_l at g + l * g_stride, rows of P floats, l = 1 .. L: g_lin_L is
+                                                          // read, g_lin_{L-1} .. g_lin_1 are written (buffers padded to 128 rows)
+  unsigned* gamax = nullptr;                              // max |g_lin_l| slots at gamax + l * WIRE_AMAX_SLOTS (L: read; below: written)
+  const float* aux = nullptr; long long aux_stride = 0;   // lin_l (relu: out_l) at aux + l * aux_stride, l = 1 .. L - 1
+  const unsigned char* wimg = nullptr;                    // k-permuted images of the TRANSPOSED weights, layers L, L - 1, .. 2 back to back
+  const unsigned* wamax = nullptr; int wamax_stride = 0;  // max |W_l| slots of layer l at wamax + (l - 1) * wamax_stride
+  int L = 0;
+  float w = 0.f, s = 0.f;                                 // hidden omega_0, scale_0
+};
+bool fused_bwd_enabled();
+bool fused_bwd_shape(int kind, int P);
+hipError_t launch_fused_bwd(hipStream_t s, int kind, int P, const FusedBwdParams& fp);
