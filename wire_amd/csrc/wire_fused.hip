@@ -170,13 +170,13 @@ struct FxCtx {
   int ys;                     // vector-memory operations issued since the last weight-stream issue (stores: counted waits)
 };
 
-template <int NB, int RING, typename PT>
+template <int NB, int RING, typename PT, int W = FX_WAVES>
 WIRE_DEVINL void fx_issue(const PT& fp, const FxCtx& c, int t, int buf) {
-  constexpr int STAGE = NB * 2048, PIECES = NB / 4;
+  constexpr int STAGE = NB * 2048, PIECES = 2 * NB / W;   // 1 KB pieces per wave: the W waves of a workgroup share a stage
   const unsigned char* src = fp.wimg + (size_t)t * STAGE + c.wave * 1024 + c.lane * 16;
   unsigned char* dst = c.ring + buf * STAGE + c.wave * 1024;
 #pragma unroll
-  for (int j = 0; j < PIECES; ++j) fx_dma16(src + j * 8192, dst + j * 8192);
+  for (int j = 0; j < PIECES; ++j) fx_dma16(src + j * (W * 1024), dst + j * (W * 1024));
 }
 
 // top of a stage: this wave's pieces of stage c.t have landed, then everybody's (barrier); the buffer that the barrier
@@ -197,9 +197,9 @@ WIRE_DEVINL void fx_wait_vm(const int n) {
 // `younger` = vector-memory operations that were CERTAINLY issued after the pieces of stage c.t (the training forward's
 // stores and, with RING = 3, the pieces of stage c.t + 1): the wait may leave exactly those in flight.  Never more than were
 // issued -- a count that is too high would let a piece of stage c.t stay in flight.
-template <int NB, int RING, int ABL, typename PT>
+template <int NB, int RING, int ABL, typename PT, int W = FX_WAVES>
 WIRE_DEVINL void fx_stage_top(const PT& fp, FxCtx& c, const int younger_stores) {
-  constexpr int PIECES = NB / 4;
+  constexpr int PIECES = 2 * NB / W;
   if constexpr (!(ABL & 4)) {
     if (RING == 3 && c.t + 1 < c.T) fx_wait_vm(PIECES + younger_stores);
     else fx_wait_vm(younger_stores);
@@ -210,7 +210,7 @@ WIRE_DEVINL void fx_stage_top(const PT& fp, FxCtx& c, const int younger_stores) 
     nb = nb >= RING ? nb - RING : nb;
     // (the probe keeps the branch: it is what ends the scheduling region of a stage)
     if constexpr (ABL & 4) asm volatile("s_nop 0");
-    else fx_issue<NB, RING>(fp, c, c.t + RING - 1, nb);
+    else fx_issue<NB, RING, PT, W>(fp, c, c.t + RING - 1, nb);
   }
 }
 
@@ -684,8 +684,8 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwd
 // MFMAs; the two waves of a SIMD overlap instead.  The last link (layer 1: the first layer's sums) stays with the
 // layer-by-layer kernel (wire_gemmh_epi.h, cr_partial).
 // ---------------------------------------------------------------------------
-template <int KIND, int NB, int RING>
-__global__ __launch_bounds__(64 * FX_WAVES) void fused_bwd_kernel(const FusedBwdParams fp) {
+template <int KIND, int NB, int RING, int W>
+__global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwdParams fp) {
   constexpr int ACT = FxKind<KIND>::ACT;
   constexpr int P = 16 * NB, S = NB / 2, STAGE = NB * 2048;
   static_assert(!FxKind<KIND>::CPLX, "real nets");
@@ -696,13 +696,13 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_bwd_kernel(const FusedBwd
   c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   c.g = c.lane >> 4;
   c.n = fp.n;
-  c.row = (long long)blockIdx.x * FX_ROWS + c.wave * 16 + (c.lane & 15);
+  c.row = (long long)blockIdx.x * (16 * W) + c.wave * 16 + (c.lane & 15);
   c.ring = fx_smem;
   const int links = fp.L - 1;                            // layers L .. 2
   c.t = 0; c.T = links * S; c.buf = 0;
   c.ys = 0;
-  fx_issue<NB, RING>(fp, c, 0, 0);
-  if (RING == 3 && c.T > 1) fx_issue<NB, RING>(fp, c, 1, 1);
+  fx_issue<NB, RING, FusedBwdParams, W>(fp, c, 0, 0);
+  if (RING == 3 && c.T > 1) fx_issue<NB, RING, FusedBwdParams, W>(fp, c, 1, 1);
   const size_t ro = (size_t)c.row * P + 4 * c.g;         // this lane's first column of block 0 (rows are padded to 128)
 
   // ---- the first operand: g_lin_L from memory, scaled by its tensor maximum (published by the final stage)
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_bwd_kernel(const FusedBwd
     (void)sB;
 #pragma unroll
     for (int j = 0; j < S; ++j) {
-      fx_stage_top<NB, RING, 0>(fp, c, RING == 3 ? ys1 + ys0 : ys0);
+      fx_stage_top<NB, RING, 0, FusedBwdParams, W>(fp, c, RING == 3 ? ys1 + ys0 : ys0);
       ys1 = ys0; ys0 = 0;
       const unsigned char* Sb = c.ring + c.buf * STAGE + c.lane * 16;
       const fx_f16x8 ah = __builtin_bit_cast(fx_f16x8, Fh[j]), al = __builtin_bit_cast(fx_f16x8, Fl[j]);
@@ -823,6 +823,7 @@ static std::atomic<int> g_fused_train{fx_env("WIRE_FUSED_TRAIN", 1)};
 bool fused_train_enabled() { return g_fused_train != 0 && g_fused_fwd != 0; }
 int fused_bwd_knob();
 void fused_bwd_knob_set(int v);
+void fused_bwd_w_set(int v);
 int fused_tune_get(const char* key) {
   if (!strcmp(key, "fused_fwd")) return g_fused_fwd;
   if (!strcmp(key, "fused_train")) return g_fused_train;
@@ -833,6 +834,7 @@ int fused_tune_set(const char* key, int value) {
   if (!strcmp(key, "fused_fwd") && value >= 0 && value <= 1) { g_fused_fwd = value; return 0; }
   if (!strcmp(key, "fused_train") && value >= 0 && value <= 1) { g_fused_train = value; return 0; }
   if (!strcmp(key, "fused_bwd") && value >= 0 && value <= 1) { fused_bwd_knob_set(value); return 0; }
+  if (!strcmp(key, "fused_bwd_w") && (value == 4 || value == 8)) { fused_bwd_w_set(value); return 0; }
 #ifdef WIRE_FX_ABLATE
   if (!strcmp(key, "fx_ablate") && value >= 0 && value <= 15) { g_fx_ablate = value; return 0; }
 #endif
@@ -918,15 +920,24 @@ template __global__ void fused_fwd_kernel<NK_SIREN, 16, 3, FX_PROBE_ABL>(const F
 static std::atomic<int> g_fused_bwd{fx_env("WIRE_FUSED_BWD", 1)};
 bool fused_bwd_enabled() { return g_fused_bwd != 0 && fused_train_enabled(); }
 bool fused_bwd_shape(int kind, int P) { return (kind == NK_SIREN || kind == NK_GAUSS || kind == NK_RELU) && P == 256; }
-template <int KIND>
-static hipError_t fxb_launch_t(hipStream_t s, const FusedBwdParams& fp) {
-  constexpr int NB = 16, RING = 3, LDS = RING * NB * 2048;
-  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_bwd_kernel<KIND, NB, RING>),
+// W = waves per workgroup.  8: one workgroup per CU, ring of three stages.  4: TWO workgroups of 64 rows per CU, each with
+// a ring of two stages (2 x 64 KB of LDS) -- they share nothing, so one's epilogue (no MFMAs: the link's activation
+// derivative, maxima, splits) runs beside the other's MFMAs, which the two waves of a SIMD inside ONE workgroup cannot do
+// (they meet at every stage barrier); price: the weight stream is fetched per 64 rows instead of per 128.
+static std::atomic<int> g_fused_bwd_w{fx_env("WIRE_FUSED_BWD_W", 8)};   // (A/B on three nets, two rounds each: no difference -- profiles/r04_fused_bwd_w_ab.txt)
+template <int KIND, int W>
+static hipError_t fxb_launch_w(hipStream_t s, const FusedBwdParams& fp) {
+  constexpr int NB = 16, RING = W == 8 ? 3 : 2, LDS = RING * NB * 2048;
+  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_bwd_kernel<KIND, NB, RING, W>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (attr != hipSuccess) return attr;
-  const unsigned grid = (unsigned)((fp.n + FX_ROWS - 1) / FX_ROWS);
-  hipLaunchKernelGGL((fused_bwd_kernel<KIND, NB, RING>), dim3(grid), dim3(64 * FX_WAVES), LDS, s, fp);
+  const unsigned grid = (unsigned)((fp.n + 16 * W - 1) / (16 * W));
+  hipLaunchKernelGGL((fused_bwd_kernel<KIND, NB, RING, W>), dim3(grid), dim3(64 * W), LDS, s, fp);
   return hipGetLastError();
+}
+template <int KIND>
+static hipError_t fxb_launch_t(hipStream_t s, const FusedBwdParams& fp) {
+  return g_fused_bwd_w == 8 ? fxb_launch_w<KIND, 8>(s, fp) : fxb_launch_w<KIND, 4>(s, fp);
 }
 hipError_t launch_fused_bwd(hipStream_t s, int kind, int P, const FusedBwdParams& fp) {
   if (fp.n <= 0 || fp.L < 2) return hipSuccess;
@@ -941,3 +952,4 @@ hipError_t launch_fused_bwd(hipStream_t s, int kind, int P, const FusedBwdParams
 }
 int fused_bwd_knob() { return g_fused_bwd; }
 void fused_bwd_knob_set(int v) { g_fused_bwd = v; }
+void fused_bwd_w_set(int v) { g_fused_bwd_w = v; }
