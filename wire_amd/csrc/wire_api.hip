@@ -126,6 +126,8 @@ static std::atomic<int> g_split_f16{env_flag("WIRE_SPLIT_F16", 1)};
 // pairs by the epilogue that produces them (wire_dev.h: wire_store_out4), so the GEMMs that read them -- the next layer's
 // forward, the weight gradient -- spend no vector instructions on the split (out_split_scale below)
 static std::atomic<int> g_split_out{env_flag("WIRE_SPLIT_OUT", 1)};
+// with the fused training forward + data-gradient chain of a sine / Gaussian net: store r = c lin and no out_l ("fused_rstore")
+static std::atomic<int> g_fused_rstore{env_flag("WIRE_FUSED_RSTORE", 1)};
 // family the flags select for a net kind (wire_layer_api.hip): 2 split-bf16, 1 complex 3M (wire only), 0 4M
 int wire_family_(int kind) {
   if (g_split_bf16) return 2;
@@ -137,6 +139,7 @@ extern "C" int wire_tune_get(const char* key) {
   if (!strcmp(key, "complex_3m")) return g_complex_3m;
   if (!strcmp(key, "split_bf16")) return g_split_bf16;
   if (!strcmp(key, "split_out")) return g_split_out;
+  if (!strcmp(key, "fused_rstore")) return g_fused_rstore;
   if (!strcmp(key, "x3_h16")) return gemmx3h_mode();
   if (!strcmp(key, "x3_tn16")) return gemmx3_tn16_mode();
   if (!strcmp(key, "recompute_out")) return g_recompute_out;
@@ -153,6 +156,7 @@ extern "C" int wire_tune_set(const char* key, int value) {
   if (!strcmp(key, "first_sums")) { g_first_sums = value ? 1 : 0; return WIRE_OK; }
   if (!strcmp(key, "split_f16")) { g_split_f16 = value ? 1 : 0; return WIRE_OK; }
   if (!strcmp(key, "split_out")) { g_split_out = value ? 1 : 0; return WIRE_OK; }
+  if (!strcmp(key, "fused_rstore")) { g_fused_rstore = value ? 1 : 0; return WIRE_OK; }
   if (gemmx2h_tune_set(key, value) == 0) return WIRE_OK;
   if (fused_tune_set(key, value) == 0) return WIRE_OK;
   if (gemm_tune_set(key, value) == 0) return WIRE_OK;
@@ -365,6 +369,11 @@ bool fused_train_applies(const Plan& p, int64_t n) {
 // stays with the layer-by-layer kernel)
 bool fused_bwd_applies(const Plan& p, int64_t n) {
   return fused_bwd_enabled() && p.off_fxd >= 0 && p.L >= 2 && fused_train_applies(p, n);
+}
+// ... and then the sine / Gaussian nets store NO inner out_l and their inner lin_l as r = c lin (the argument the activation
+// was evaluated on): the chain differentiates on r, the weight-gradient loader evaluates act(r) again -- 0.8 GB per step less
+bool fused_rstore(const Plan& p, int64_t n) {
+  return (p.kind == WIRE_KIND_SIREN || p.kind == WIRE_KIND_GAUSS) && g_fused_rstore && fused_bwd_applies(p, n);
 }
 float out_split_scale(const Plan& p, int64_t n, int l) {
   if (!g_split_out || l < 1 || l >= p.L || p.kind == WIRE_KIND_RELU) return 0.f;
@@ -609,6 +618,7 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
     fp.lin = p.kind == WIRE_KIND_RELU ? nullptr : A + a.lin1; fp.lin_stride = a.np * p.Pl;
     fp.out = A + a.out0; fp.out_stride = a.np * p.P;
     fp.amax_out = amax;
+    fp.rstore = fused_rstore(p, n) ? 1 : 0;
     ProfScope ps(s, 0, 2.0 * n * p.Pl * p.P * p.L);
     HIPCHK(launch_fused_fwd(s, p.kind, p.P, fp));
     return WIRE_OK;
@@ -768,6 +778,7 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
     bp.wimg = reinterpret_cast<const unsigned char*>(packed + p.off_fxd);
     bp.wamax = reinterpret_cast<const unsigned*>(packed + p.off_wamax) + WIRE_AMAX_SLOTS; bp.wamax_stride = WIRE_AMAX_SLOTS;
     bp.L = p.L; bp.w = p.w; bp.s = p.s;
+    bp.rstore = fused_rstore(p, n) ? 1 : 0; bp.c_hidden = fused_pre_scale(p.kind, p.w, p.s);
     ProfScope ps(s, 1, 2.0 * n * p.Pl * p.P * (p.L - 1));
     HIPCHK(launch_fused_bwd(s, p.kind, p.P, bp));
   }
@@ -791,7 +802,12 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
       const int S = x2tn ? gemmx2_tn_splits(n, p.Pl, p.P, sc.S)
                          : (p.x3 ? gemmx3_tn_splits(n, p.Pl, p.P, sc.S) : gemm_tn_splits(n, p.Pl, p.P, sc.S));
       { ProfScope ps(s, 2, 2.0 * n * p.Pl * p.P);
-        if (x2tn) {
+        if (x2tn && chain && l >= 2 && fused_rstore(p, n)) {
+          // Z = act(r_{l-1}) evaluated by the loader from the stored pre-activation (no out_{l-1} exists), scale 2^14
+          HIPCHK(launch_gemmx2_tn(s, gcur, p.Pl, lin_l(l - 1), p.Pl, n, p.Pl, p.P, S, Sx + sc.slab, Sx + sc.bslab,
+                                  gamax + l * WIRE_AMAX_SLOTS, nullptr, 1.f / 16384.f,
+                                  p.kind == WIRE_KIND_SIREN ? 2 : 3));
+        } else if (x2tn) {
           const float s_z = out_split_scale(p, n, l - 1);
           HIPCHK(launch_gemmx2_tn(s, gcur, p.Pl, out_l(l - 1), p.P, n, p.Pl, p.P, S, Sx + sc.slab, Sx + sc.bslab,
                                   gamax + l * WIRE_AMAX_SLOTS, amax + (l - 1) * WIRE_AMAX_SLOTS,

@@ -186,11 +186,15 @@ WIRE_DEVINL void fx_issue(const PT& fp, const FxCtx& c, int t, int buf) {
 // s_waitcnt vmcnt(n) for a value that is a constant only after unrolling (the immediate must be a literal)
 WIRE_DEVINL void fx_wait_vm(const int n) {
 #define FX_VM_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-  switch (n < 0 ? 0 : (n > 24 ? 24 : n)) {
+  // (vmcnt has 6 bits; a count above 48 is clamped -- waiting for more than necessary is always safe)
+  switch (n < 0 ? 0 : (n > 48 ? 48 : n)) {
     FX_VM_CASE(0) FX_VM_CASE(1) FX_VM_CASE(2) FX_VM_CASE(3) FX_VM_CASE(4) FX_VM_CASE(5) FX_VM_CASE(6) FX_VM_CASE(7)
     FX_VM_CASE(8) FX_VM_CASE(9) FX_VM_CASE(10) FX_VM_CASE(11) FX_VM_CASE(12) FX_VM_CASE(13) FX_VM_CASE(14) FX_VM_CASE(15)
     FX_VM_CASE(16) FX_VM_CASE(17) FX_VM_CASE(18) FX_VM_CASE(19) FX_VM_CASE(20) FX_VM_CASE(21) FX_VM_CASE(22) FX_VM_CASE(23)
-    default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    FX_VM_CASE(24) FX_VM_CASE(25) FX_VM_CASE(26) FX_VM_CASE(27) FX_VM_CASE(28) FX_VM_CASE(29) FX_VM_CASE(30) FX_VM_CASE(31)
+    FX_VM_CASE(32) FX_VM_CASE(33) FX_VM_CASE(34) FX_VM_CASE(35) FX_VM_CASE(36) FX_VM_CASE(37) FX_VM_CASE(38) FX_VM_CASE(39)
+    FX_VM_CASE(40) FX_VM_CASE(41) FX_VM_CASE(42) FX_VM_CASE(43) FX_VM_CASE(44) FX_VM_CASE(45) FX_VM_CASE(46) FX_VM_CASE(47)
+    default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
   }
 #undef FX_VM_CASE
 }
@@ -291,7 +295,7 @@ template <int KIND, int NB> constexpr int fx_nparts() { return FxKind<KIND>::CPL
 // its last activation (fp32) or after its last split (the very registers of the fragment: wire_store_out4's format at scale
 // 1).  Stores are unconditional (rows beyond n land in the padding rows of the act buffer: wire_api.hip act_layout): their
 // number per stage is what the counted wait of the weight stream relies on.  Returns the number of stores it issued.
-template <int KIND, int NB, bool FROM_COORDS, bool TRAIN>
+template <int KIND, int NB, bool FROM_COORDS, int TRAIN>
 WIRE_DEVINL int fx_slice(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)[NB], const int l_src,
                          const float a_scale, const int j, const int cb, f32x4 (&w)[4], fx_u32x4 (&Fh)[NB / 2],
                          fx_u32x4 (&Fl)[NB / 2]) {
@@ -299,9 +303,10 @@ WIRE_DEVINL int fx_slice(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)[
   constexpr int P = 16 * NB, PF = CPLX ? P / 2 : P, NP = fx_nparts<KIND, NB>();
   // what a training forward stores of the layer in production (compile-time: the store count per stage is part of the
   // weight stream's wait): lin unless relu / wire's real layer 0; out fp32 for layer 0 and relu, else the split pairs
+  // (TRAIN = 2, sine / Gaussian nets whose backward is the chain: the inner layers store r itself and no out at all)
   constexpr bool ST_LIN = TRAIN && KIND != NK_RELU && (!FROM_COORDS || !CPLX);
   constexpr bool ST_F32 = TRAIN && (KIND == NK_RELU || FROM_COORDS);
-  constexpr bool ST_SPLIT = TRAIN && !ST_F32;
+  constexpr bool ST_SPLIT = TRAIN == 1 && !ST_F32;
   if constexpr (CPLX) {
     constexpr int ST = NB / 9;                            // block stride between steps
     const int q = 2 + j;
@@ -448,7 +453,7 @@ WIRE_DEVINL float fx_wave_scale(const FusedFwdParams& fp, const FxCtx& c, const 
 // hidden layer l (1 .. L):  dst = h_{l-1} W_l^T  with the operands' scales still on it; h_{l-1} comes from the coordinates
 // (l = 1) or from `src`, the accumulators of layer l - 1.  During the MFMAs of stage j the vector unit produces what stage
 // j + 1 (real nets: parts 2 j + 2, 2 j + 3) or the stage pair after the current one (wire: part j + 2) will consume.
-template <int KIND, int NB, int RING, bool FROM_COORDS, int ABL, bool TRAIN>
+template <int KIND, int NB, int RING, bool FROM_COORDS, int ABL, int TRAIN>
 WIRE_DEVINL void fx_layer(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)[NB], f32x4 (&dst)[NB], const int l) {
   constexpr bool CPLX = FxKind<KIND>::CPLX;
   constexpr int S = NB / 2, STAGE = NB * 2048, P = 16 * NB;
@@ -462,7 +467,7 @@ WIRE_DEVINL void fx_layer(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)
       c.st_lin = (FROM_COORDS ? fp.lin0 : fp.lin + (size_t)(ls - 1) * fp.lin_stride) + ro;
     c.st_out = fp.out + (size_t)ls * fp.out_stride + ro;
     c.st_split = KIND != NK_RELU && !FROM_COORDS;
-    c.st_inv_c = ls == 0 ? fp.inv_c_first : fp.inv_c_hidden;
+    c.st_inv_c = FROM_COORDS ? fp.inv_c_first : (TRAIN == 2 ? 1.f : fp.inv_c_hidden);
     c.amx = 0.f;
   }
   float sA = 1.f, invA = 1.f;                          // (bounded activations are split unscaled)
@@ -607,7 +612,7 @@ constexpr int fx_lds_bytes() {
   return RING * NB * 2048 + (4 * 16 * NB + 16 * NB + FX_LMAX * 16 * NB + 4 * 16 * NB) * 4;   // (first layer sized for PF = P)
 }
 
-template <int KIND, int NB, int RING, int ABL = 0, bool TRAIN = false>
+template <int KIND, int NB, int RING, int ABL = 0, int TRAIN = 0>
 __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwdParams fp) {
   constexpr bool CPLX = FxKind<KIND>::CPLX;
   constexpr int P = 16 * NB, PF = CPLX ? P / 2 : P, S = NB / 2, STAGE = NB * 2048;
@@ -784,10 +789,21 @@ __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwd
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float go = acc[cb][e] * inv;
-        float out = 0.f;
-        if (ACT == ACT_GAUSS) out = real_act_fwd_lean<ACT_GAUSS>(aux[cb][e], fp.w, fp.s);
-        if (ACT == ACT_RELU) out = aux[cb][e];
-        gl[e] = valid ? real_act_bwd_lean<ACT>(go, aux[cb][e], out, fp.w, fp.s) : 0.f;
+        float v;
+        if (fp.rstore && ACT == ACT_SIREN) {
+          // aux = r = omega lin / 2 pi: d sin(omega lin) / d lin = omega cos(2 pi r)
+          v = go * fp.w * __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(aux[cb][e]));
+        } else if (fp.rstore && ACT == ACT_GAUSS) {
+          // aux = r = s sqrt(log2 e) lin: out = exp2(-r^2), d out / d lin = -2 s^2 lin out = -(2 s^2 / c) r out
+          const float r = aux[cb][e];
+          v = go * __builtin_amdgcn_exp2f(-(r * r)) * (-2.f * fp.s * fp.s / fp.c_hidden) * r;
+        } else {
+          float out = 0.f;
+          if (ACT == ACT_GAUSS) out = real_act_fwd_lean<ACT_GAUSS>(aux[cb][e], fp.w, fp.s);
+          if (ACT == ACT_RELU) out = aux[cb][e];
+          v = real_act_bwd_lean<ACT>(go, aux[cb][e], out, fp.w, fp.s);
+        }
+        gl[e] = valid ? v : 0.f;
         amx = __builtin_fmaxf(amx, __builtin_fabsf(gl[e]));
       }
       *reinterpret_cast<f32x4*>(gp + 16 * cb) = gl;
@@ -862,10 +878,20 @@ static hipError_t fx_launch_t(hipStream_t s, const FusedFwdParams& fp) {
   const unsigned grid = (unsigned)((fp.n + FX_ROWS - 1) / FX_ROWS);
   if (fp.out != nullptr) {                               // training forward: stores what the backward reads
     if constexpr (ABL == 0) {
-      const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_kernel<KIND, NB, RING, 0, true>),
+      if constexpr (KIND == NK_SIREN || KIND == NK_GAUSS) {
+        if (fp.rstore) {
+          const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_kernel<KIND, NB, RING, 0, 2>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+          if (attr != hipSuccess) return attr;
+          hipLaunchKernelGGL((fused_fwd_kernel<KIND, NB, RING, 0, 2>), dim3(grid), dim3(64 * FX_WAVES), LDS, s, fp);
+          return hipGetLastError();
+        }
+      }
+      if (fp.rstore) return hipErrorInvalidValue;
+      const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_kernel<KIND, NB, RING, 0, 1>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       if (attr != hipSuccess) return attr;
-      hipLaunchKernelGGL((fused_fwd_kernel<KIND, NB, RING, 0, true>), dim3(grid), dim3(64 * FX_WAVES), LDS, s, fp);
+      hipLaunchKernelGGL((fused_fwd_kernel<KIND, NB, RING, 0, 1>), dim3(grid), dim3(64 * FX_WAVES), LDS, s, fp);
       return hipGetLastError();
     } else {
       return hipErrorInvalidValue;

@@ -132,7 +132,7 @@ bool gemmx2_tn_applies(int Pm, int Pn);
 int gemmx2_tn_splits(int64_t n, int Pm, int Pn, int max_splits);
 hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n, int Pm,
                             int Pn, int splits, float* slab, float* bslab, const unsigned* amax_g,
-                            const unsigned* amax_z, float z_pre_inv = 0.f);
+                            const unsigned* amax_z, float z_pre_inv = 0.f, int z_act = 0);
 
 // ---- whole-net forward in one kernel (wire_fused.hip): activations stay in the wave's registers from the coordinates to
 // the output; the hidden layers' weights come from a k-permuted edition of the 2 x fp16 image (same maximum slots)
@@ -163,6 +163,9 @@ struct FusedFwdParams {
                                                           // pairs at scale 1 (relu: fp32, and out_L too)
   unsigned* amax_out = nullptr;                           // max |out_l| slots at amax_out + l * WIRE_AMAX_SLOTS (fp32-stored layers)
   float inv_c_first = 1.f, inv_c_hidden = 1.f;            // 1 / c: lin is stored in the reference's units
+  int rstore = 0;                                         // sine / Gaussian nets with the data-gradient chain: lin_1 .. lin_{L-1} are
+                                                          // stored AS r = c lin and out_1 .. out_{L-1} not at all -- the chain and the
+                                                          // weight-gradient loader (launch_gemmx2_tn, z_act) evaluate on r
 };
 bool fused_train_enabled();
 float fused_pre_scale(int kind, float omega0, float scale0);   // the c of a layer with these hyper-parameters
@@ -183,6 +186,7 @@ struct FusedBwdParams {
   const unsigned* wamax = nullptr; int wamax_stride = 0;  // max |W_l| slots of layer l at wamax + (l - 1) * wamax_stride
   int L = 0;
   float w = 0.f, s = 0.f;                                 // hidden omega_0, scale_0
+  int rstore = 0; float c_hidden = 1.f;                   // aux holds r = c lin (FusedFwdParams::rstore), c
 };
 bool fused_bwd_enabled();
 bool fused_bwd_shape(int kind, int P);

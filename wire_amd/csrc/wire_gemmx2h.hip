@@ -561,7 +561,11 @@ WIRE_DEVINL x2s16x4 x2_lds_tr16(const unsigned char* p) {
       (x2s16x4 __attribute__((address_space(3)))*)(const_cast<unsigned char*>(p)));
 }
 
-template <int WM, int WN, bool ZPRE>
+// ZMODE: what the Z rows hold -- 0: fp32 values (scale from their maximum slots); 1: pre-split fp16 pairs (wire_dev.h:
+// wire_store_out4; 1 / scale from the host); 2 / 3 (round 4, the fused training forward of siren / gauss nets stores no out_l at
+// all): the pre-activation r = c lin the forward's activation was evaluated on -- the loader evaluates sin(2 pi r) (2) or
+// exp2(-r^2) (3) again, the very instructions of wire_fused.hip's producer, and splits with the fixed scale 1 / z_pre_inv.
+template <int WM, int WN, int ZMODE>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
     const float* __restrict__ G, int ldg, const float* __restrict__ Z, int ldz, long long n, int Pm, int Pn,
     int tiles_n, int nsplit, long long chunk, float* __restrict__ slab, float* __restrict__ bslab, int tiles,
@@ -594,7 +598,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
   // ZPRE: Z is a pre-split activation (wire_dev.h: wire_store_out4) -- the 16 bytes a loader lane reads are the 8 + 8 bytes
   // it stores into the h and l planes; 1 / its scale comes from the host.  (A template parameter: as a run-time branch of
   // the loader it costs the (WM, 1) shapes 199 spilled registers.)
-  if constexpr (ZPRE) { s_z = 1.f; inv_z = z_pre_inv; }
+  constexpr bool ZPRE = ZMODE == 1;
+  if constexpr (ZMODE >= 1) { s_z = 1.f / z_pre_inv; inv_z = z_pre_inv; }
   else wire_x2_scales(wire_amax_read(amax_z, lane), s_z, inv_z);
 
   // loader lane = (block of the pair, row slot 0-7, feature quad); unit pair u = (block pair u % P, pass u / P); pass t
@@ -685,8 +690,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
           const x2u32x4 zu = __builtin_bit_cast(x2u32x4, zv);
           h0 = zu[0]; h1 = zu[1]; l0 = zu[2]; l1 = zu[3];
         } else {
-          x2_split2(zv[0], zv[1], s_z, h0, l0);
-          x2_split2(zv[2], zv[3], s_z, h1, l1);
+          f32x4 zz = zv;
+          if constexpr (ZMODE == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) zz[e] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(zv[e]));
+          }
+          if constexpr (ZMODE == 3) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) zz[e] = __builtin_amdgcn_exp2f(-(zv[e] * zv[e]));
+          }
+          x2_split2(zz[0], zz[1], s_z, h0, l0);
+          x2_split2(zz[2], zz[3], s_z, h1, l1);
         }
         unsigned char* d = S + 2 * GPLANE + fp * 2048 + t * 256;
         *reinterpret_cast<x2u32x2*>(d) = x2u32x2{h0, h1};
@@ -844,36 +858,45 @@ int gemmx2_tn_splits(int64_t n, int Pm, int Pn, int max_splits) {
   return s < 1 ? 1 : s;
 }
 
-template <int WM, int WN>
-static hipError_t launch_x2_tn_t(hipStream_t s, dim3 grid, const float* G, int ldg, const float* Z, int ldz, int64_t n,
+template <int WM, int WN, int ZMODE>
+static hipError_t launch_x2_tn_z(hipStream_t s, dim3 grid, const float* G, int ldg, const float* Z, int ldz, int64_t n,
                                  int Pm, int Pn, int tiles_n, int used, long long chunk, float* slab, float* bslab,
                                  int tiles, const unsigned* amax_g, const unsigned* amax_z, float z_pre_inv) {
   constexpr int STAGE = X2T_TK * (64 * WM + 128 * WN) * 4;
   // > 64 KB of dynamic LDS needs the opt-in; per launch (a host-side call of about a microsecond), because the attribute
   // belongs to the current device's copy of the function and a process may drive more than one
-  if (z_pre_inv != 0.f) {
-    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemmx2_tn16_kernel<WM, WN, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
-    if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((gemmx2_tn16_kernel<WM, WN, true>), grid, dim3(64 * WM * WN), 2 * STAGE, s, G, ldg, Z, ldz,
-                       (long long)n, Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles, amax_g, amax_z, z_pre_inv);
-    return hipGetLastError();
-  }
-  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemmx2_tn16_kernel<WM, WN, false>),
+  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemmx2_tn16_kernel<WM, WN, ZMODE>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
   if (attr != hipSuccess) return attr;
-  hipLaunchKernelGGL((gemmx2_tn16_kernel<WM, WN, false>), grid, dim3(64 * WM * WN), 2 * STAGE, s, G, ldg, Z, ldz,
+  hipLaunchKernelGGL((gemmx2_tn16_kernel<WM, WN, ZMODE>), grid, dim3(64 * WM * WN), 2 * STAGE, s, G, ldg, Z, ldz,
                      (long long)n, Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles, amax_g, amax_z, z_pre_inv);
   return hipGetLastError();
+}
+template <int WM, int WN>
+static hipError_t launch_x2_tn_t(hipStream_t s, dim3 grid, const float* G, int ldg, const float* Z, int ldz, int64_t n,
+                                 int Pm, int Pn, int tiles_n, int used, long long chunk, float* slab, float* bslab,
+                                 int tiles, const unsigned* amax_g, const unsigned* amax_z, float z_pre_inv, int z_act) {
+#define X2_TN_Z(M) launch_x2_tn_z<WM, WN, M>(s, grid, G, ldg, Z, ldz, n, Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles, amax_g, \
+                                            amax_z, z_pre_inv)
+  if constexpr (WM == 4 && WN == 2) {                      // the re-evaluating loaders: the 256-feature real nets only
+    if (z_act == 2) return X2_TN_Z(2);
+    if (z_act == 3) return X2_TN_Z(3);
+  }
+  if (z_act >= 2) return hipErrorInvalidValue;
+  return z_pre_inv != 0.f ? X2_TN_Z(1) : X2_TN_Z(0);
+#undef X2_TN_Z
 }
 
 // `splits` from gemmx2_tn_splits; slabs [splits][Pm][Pn] (+ bslab [splits][Pm]) as launch_gemmx3_tn writes them.
 // z_pre_inv != 0: Z is a pre-split activation (wire_dev.h: wire_store_out4), 1 / its scale; amax_z is not read.
+// z_act = 2 / 3: Z holds the pre-activation r of a sine / Gaussian layer as wire_fused.hip stored it; the loader evaluates the
+// activation again and splits with scale 1 / z_pre_inv (which must be given).
 hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n, int Pm,
                             int Pn, int splits, float* slab, float* bslab, const unsigned* amax_g,
-                            const unsigned* amax_z, float z_pre_inv) {
+                            const unsigned* amax_z, float z_pre_inv, int z_act) {
   const int shp = x2_tn_shape(Pm, Pn);
-  if (!shp || (ldg & 3) || (ldz & 3) || splits < 1 || n < 1 || !amax_g || (!amax_z && z_pre_inv == 0.f))
+  if (!shp || (ldg & 3) || (ldz & 3) || splits < 1 || n < 1 || !amax_g || (!amax_z && z_pre_inv == 0.f) ||
+      (z_act != 0 && (z_act < 2 || z_act > 3 || z_pre_inv == 0.f)))
     return hipErrorInvalidValue;
   const int TMf = 64 * (shp / 10), TNf = 128 * (shp % 10);
   const int tiles_m = Pm / TMf, tiles_n = (Pn + TNf - 1) / TNf;
@@ -890,7 +913,7 @@ hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float*
       if (e != hipSuccess) return e;
     }
   }
-#define X2_TN_ARGS s, grid, G, ldg, Z, ldz, n, Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles_m * tiles_n, amax_g, amax_z, z_pre_inv
+#define X2_TN_ARGS s, grid, G, ldg, Z, ldz, n, Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles_m * tiles_n, amax_g, amax_z, z_pre_inv, z_act
   switch (shp) {
     case 42: return launch_x2_tn_t<4, 2>(X2_TN_ARGS);
     case 61: return launch_x2_tn_t<6, 1>(X2_TN_ARGS);
