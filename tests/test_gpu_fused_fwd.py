@@ -31,16 +31,20 @@ CASES = {
     "wire_k181_classdef": (dict(nonlin="wire", hidden_features=256, first_omega_0=30.0, hidden_omega_0=30.0, scale=10.0), 4),
     "wire_k128_3x": (dict(nonlin="wire", hidden_features=182, first_omega_0=7.0, hidden_omega_0=7.0, scale=6.0), 3),
     "wire_k90_2x_cfg1": (dict(nonlin="wire", hidden_features=128, first_omega_0=7.0, hidden_omega_0=7.0, scale=6.0), 2),
+    # positional encoding (modules/relu.py:62-75, sidelength 512 -> 7 frequencies, 30 -> 64 padded features): layer 0 is a GEMM
+    # layer of the kernel, its operand evaluated in the lanes
+    "relu_posenc_4x256": (dict(nonlin="relu", hidden_features=256, pos_encode=True, sidelength=512), 4),
+    "relu_posenc_1x256": (dict(nonlin="relu", hidden_features=256, pos_encode=True, sidelength=512), 1),
 }
 
 
-def _oracle(kind, P, coords, L, om1, om, sc, double):
+def _oracle(kind, P, coords, L, om1, om, sc, double, nf=None):
     p = wo.cast_params(P, double)
     rdt = np.float64 if double else np.float32
     c = coords.astype(rdt)
     if kind == "wire":
         return wo.wire_forward(p, c, L, rdt(om1), rdt(om), rdt(sc))
-    return wo.realnet_forward(kind, p, c, L, rdt(om1), rdt(om), rdt(sc), None)
+    return wo.realnet_forward(kind, p, c, L, rdt(om1), rdt(om), rdt(sc), nf)
 
 
 @pytest.mark.parametrize("case", list(CASES))
@@ -68,8 +72,9 @@ def test_fused_forward_vs_layerwise_and_fp64_oracle(case):
     assert not np.array_equal(y_fused, y_layer), "the knob did not switch kernels"
     P = params_np(model)
     om1, om, sc = kw.get("first_omega_0", 30.0), kw.get("hidden_omega_0", 30.0), kw.get("scale", 10.0)
-    y64 = _oracle(kind, P, coords_np, Ln, om1, om, sc, True)
-    y32 = _oracle(kind, P, coords_np, Ln, om1, om, sc, False)
+    nf = wo.posenc_num_frequencies(2, kw["sidelength"]) if kw.get("pos_encode") else None
+    y64 = _oracle(kind, P, coords_np, Ln, om1, om, sc, True, nf)
+    y32 = _oracle(kind, P, coords_np, Ln, om1, om, sc, False, nf)
     err_ref = relmax(y32, y64)
     e_f, e_l = relmax(y_fused, y64), relmax(y_layer, y64)
     print(f"fused_fwd[{case}]: fused {e_f:.2e}  layer-by-layer {e_l:.2e}  numpy fp32 {err_ref:.2e}  "
@@ -103,6 +108,7 @@ TRAIN_CASES = {
     "relu_4x256": (dict(nonlin="relu", hidden_features=256), 4),
     "wire_k128_2x": (dict(nonlin="wire", hidden_features=182, first_omega_0=7.0, hidden_omega_0=7.0, scale=6.0), 2),
     "siren_1x256": (dict(nonlin="siren", hidden_features=256, first_omega_0=30.0, hidden_omega_0=30.0), 1),
+    "relu_posenc_3x256": (dict(nonlin="relu", hidden_features=256, pos_encode=True, sidelength=512), 3),
 }
 
 
@@ -145,9 +151,9 @@ def test_fused_training_forward_vs_layerwise_and_fp64_oracle(case):
     coords = wo.image_coords(*grid)[perm.numpy()]
     tgt = target.numpy()[perm.numpy()]
     om1, om, sc = kw.get("first_omega_0", 30.0), kw.get("hidden_omega_0", 30.0), kw.get("scale", 10.0)
-    masks = None
-    y64, l64, g64 = oracle_grads_chunked(kind, P, coords, tgt, Ln, om1, om, sc, True)
-    y32, l32, g32 = oracle_grads_chunked(kind, P, coords, tgt, Ln, om1, om, sc, False)
+    nf = wo.posenc_num_frequencies(2, kw["sidelength"]) if kw.get("pos_encode") else None
+    y64, l64, g64 = oracle_grads_chunked(kind, P, coords, tgt, Ln, om1, om, sc, True, nf)
+    y32, l32, g32 = oracle_grads_chunked(kind, P, coords, tgt, Ln, om1, om, sc, False, nf)
     err_y = relmax(y32, y64)
     within_ref(relmax(res[1][2], y64), err_y, f"fused_train[{case}] y")
     assert abs(res[1][0] - l64) <= (2 * abs(l32 - l64) / l64 + 1e-5) * l64
@@ -156,9 +162,13 @@ def test_fused_training_forward_vs_layerwise_and_fp64_oracle(case):
         ref = wo.as_real_pairs(g64[name]).astype(np.float64).ravel()
         ref32 = wo.as_real_pairs(g32[name]).astype(np.float64).ravel()
         mine, lay = res[1][1][off:off + ref.size], res[0][1][off:off + ref.size]
-        if kind == "relu" or name == f"net.{Ln + 1}.bias":
-            # relu: a gradient sum moves by whole terms where lin is round-off (test_gpu_timed_kernels.py: forced decisions);
-            # the final bias is the mean of dL/dy, a few nearly cancelling numbers: both against the layer-by-layer path only
-            assert relmax(mine, lay) <= 2e-5, f"{case} {name}"
+        if name == f"net.{Ln + 1}.bias":
+            # the final bias is the mean of dL/dy, a few nearly cancelling numbers: against the layer-by-layer path only
+            assert relmax(mine, lay) <= 2e-5, f"{case} {name}: {relmax(mine, lay):.3e}"
+        elif kind == "relu":
+            # relu: a gradient sum moves by whole terms where a pre-activation is round-off (the kink decisions of two correct
+            # fp32 implementations differ: test_gpu_timed_kernels.py forces them at bench size).  Here the yardstick is the
+            # worse of the two OTHER fp32 implementations at hand, numpy and the layer-by-layer kernels
+            within_ref(relmax(mine, ref), max(relmax(ref32, ref), relmax(lay, ref)), f"fused_train[{case}] grad {name}")
         else:
             within_ref(relmax(mine, ref), relmax(ref32, ref), f"fused_train[{case}] grad {name}")

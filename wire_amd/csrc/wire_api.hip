@@ -247,9 +247,11 @@ int make_plan(const wire_net_desc* d, Plan& p) {
   }
   p.off_wamax = off; off += (int64_t)(p.L + 1) * WIRE_AMAX_SLOTS;
   p.off_fx = -1;
-  if (!p.first_gemm && p.L >= 1 && fused_fwd_shape(p.kind, p.P)) { p.off_fx = off; off += (int64_t)p.L * fused_b_image_floats(p.P); }
+  // (a positional-encoding net -- relu, 64 padded encoded features -- has its GEMM first layer's image, P x 64, in front)
+  const bool fx_ok = p.L >= 1 && fused_fwd_shape(p.kind, p.P) && (!p.first_gemm || (p.kind == WIRE_KIND_RELU && p.Pin0 == 64));
+  if (fx_ok) { p.off_fx = off; off += (p.first_gemm ? (int64_t)p.P * p.Pin0 : 0) + (int64_t)p.L * fused_b_image_floats(p.P); }
   p.off_fxd = -1;
-  if (!p.first_gemm && p.L >= 2 && fused_bwd_shape(p.kind, p.P)) { p.off_fxd = off; off += (int64_t)(p.L - 1) * fused_b_image_floats(p.P); }
+  if (fx_ok && p.L >= 2 && fused_bwd_shape(p.kind, p.P)) { p.off_fxd = off; off += (int64_t)(p.L - 1) * fused_b_image_floats(p.P); }
   p.off_wf = off; off += (int64_t)p.O * p.P;
   p.off_bf = off; off += 64;
   p.off_first = off;   // native copies of the first layer's tensors (W0,b0[,V0,c0])
@@ -258,6 +260,7 @@ int make_plan(const wire_net_desc* d, Plan& p) {
   return WIRE_OK;
 }
 
+inline int64_t fx_hidden_off(const Plan& p) { return p.off_fx + (p.first_gemm ? (int64_t)p.P * p.Pin0 : 0); }
 inline int64_t first_native_off(const Plan& p, int q) {
   int64_t off = p.off_first;
   for (int i = 0; i < q; ++i) off += rup((int)p.tfloats[i], 4);
@@ -359,7 +362,7 @@ float fused_act_scale(const Plan& p);
 // family with its pre-split activations and recompute_out (the formats that kernel writes), a bound on the activations (all
 // kinds but relu).  Decides the FORMAT of the stored out_l (pre-split at scale 1), so the backward asks the same question.
 bool fused_train_applies(const Plan& p, int64_t n) {
-  if (!fused_train_enabled() || p.off_fx < 0 || p.L < 1 || p.L > 8 || p.first_gemm) return false;
+  if (!fused_train_enabled() || p.off_fx < 0 || p.L < 1 || p.L > 8) return false;
   if (!use_x2(p, n) || !gemmx2_tn_applies(p.Pl, p.P) || !g_split_out || !g_recompute_out) return false;
   if (p.kind == WIRE_KIND_WIRE && p.P > 256 && env_int_("WIRE_FUSED_TRAIN_P384", 0) == 0) return false;
   if (p.kind != WIRE_KIND_RELU && fused_act_scale(p) == 0.f) return false;
@@ -478,6 +481,13 @@ extern "C" int wire_pack_params(void* stream, const wire_net_desc* d, const void
                               packed + p.off_dg[0], packed + p.off_bias[0]));
     HIPCHK(launch_x3_split_b(s, packed + p.off_fwd[0], p.Pin0, p.Pl, p.Pin0, packed + p.off_fwd_x3[0]));
     HIPCHK(launch_x3_split_b(s, packed + p.off_dg[0], p.Pl, p.Pin0, p.Pl, packed + p.off_dg_x3[0]));
+    if (p.off_fx >= 0) {                                   // the fused forward's image of the GEMM first layer + its maximum
+      unsigned* slots0 = reinterpret_cast<unsigned*>(packed + p.off_wamax);
+      HIPCHK(launch_amax(s, packed + p.off_fwd[0], (int64_t)p.Pl * p.Pin0, slots0));
+      FxSplitBatch f0{};
+      f0.src[0] = packed + p.off_fwd[0]; f0.dst[0] = packed + p.off_fx; f0.slots[0] = slots0;
+      HIPCHK(launch_fx_split_b_batch(s, f0, 1, p.Pin0, p.P, 1.f, p.Pin0));
+    }
   }
   // hidden layers share one shape: every family's image of up to PACK_MAXB layers per launch (3 - 4 launches per step
   // instead of 4 per layer; this runs once per optimizer step and is all launch gaps)
@@ -529,7 +539,7 @@ extern "C" int wire_pack_params(void* stream, const wire_net_desc* d, const void
         for (int i = 0; i < nb; ++i) {
           const int l = l0 + i;
           fx.src[i] = packed + p.off_fwd[l];
-          fx.dst[i] = packed + p.off_fx + (int64_t)(l - 1) * fused_b_image_floats(p.P);
+          fx.dst[i] = packed + fx_hidden_off(p) + (int64_t)(l - 1) * fused_b_image_floats(p.P);
           fx.slots[i] = ab.slots[i];
         }
         HIPCHK(launch_fx_split_b_batch(s, fx, nb, p.P, p.P, fused_pre_scale(p.kind, p.w, p.s)));
@@ -581,7 +591,11 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
         fused_pre_scale(p.kind, p.w1, p.s) > 0.f && fused_pre_scale(p.kind, p.w, p.s) > 0.f) {
       FusedFwdParams fp;
       fp.coords = coords; fp.n = n;
-      fp.W0 = packed + first_native_off(p, 0); fp.b0 = packed + first_native_off(p, 1);
+      if (p.first_gemm) {
+        fp.pe_F = p.F; fp.bias0 = packed + p.off_bias[0]; fp.wamax0 = reinterpret_cast<const unsigned*>(packed + p.off_wamax);
+      } else {
+        fp.W0 = packed + first_native_off(p, 0); fp.b0 = packed + first_native_off(p, 1);
+      }
       fp.wimg = reinterpret_cast<const unsigned char*>(packed + p.off_fx);
       fp.bias = packed + p.off_bias[1]; fp.bias_stride = p.L >= 2 ? p.off_bias[2] - p.off_bias[1] : 0;
       fp.wamax = reinterpret_cast<const unsigned*>(packed + p.off_wamax) + WIRE_AMAX_SLOTS; fp.wamax_stride = WIRE_AMAX_SLOTS;
@@ -605,7 +619,14 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
     // the data-gradient epilogues and the weight-gradient GEMMs of mlp_bwd_core read (wire_fused.hip)
     FusedFwdParams fp;
     fp.coords = coords; fp.n = n;
-    fp.W0 = packed + first_native_off(p, 0); fp.b0 = packed + first_native_off(p, 1);
+    if (p.first_gemm) {
+      // the encoded features themselves are still written: the first layer's weight gradient reads them (mlp_bwd_core)
+      { ProfScope ps(s, 3, 0);
+        HIPCHK(launch_posenc(s, coords, n, p.D, p.F, p.Pin0, A + a.pe)); }
+      fp.pe_F = p.F; fp.bias0 = packed + p.off_bias[0]; fp.wamax0 = reinterpret_cast<const unsigned*>(packed + p.off_wamax);
+    } else {
+      fp.W0 = packed + first_native_off(p, 0); fp.b0 = packed + first_native_off(p, 1);
+    }
     fp.wimg = reinterpret_cast<const unsigned char*>(packed + p.off_fx);
     fp.bias = packed + p.off_bias[1]; fp.bias_stride = p.L >= 2 ? p.off_bias[2] - p.off_bias[1] : 0;
     fp.wamax = reinterpret_cast<const unsigned*>(packed + p.off_wamax) + WIRE_AMAX_SLOTS; fp.wamax_stride = WIRE_AMAX_SLOTS;

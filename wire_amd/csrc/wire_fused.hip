@@ -112,14 +112,14 @@ WIRE_DEVINL void fx_weight_scales(const unsigned* slots, int lane, float c, floa
   const float m = __uint_as_float(wire_amax_read(slots, lane)) * c;
   wire_x2_scales(__float_as_uint(m), s, inv);
 }
-__global__ void fx_split_b_kernel(FxSplitBatch sb, int ldb, int P, float c) {
+__global__ void fx_split_b_kernel(FxSplitBatch sb, int ldb, int P, int Kd, float c) {
   const float* __restrict__ Bt = sb.src[blockIdx.z];
   unsigned short* __restrict__ Fx = (unsigned short*)sb.dst[blockIdx.z];
   float s, inv;
   fx_weight_scales(sb.slots[blockIdx.z], threadIdx.x & 63, c, s, inv);
   const int k2 = (blockIdx.x * blockDim.x + threadIdx.x) * 2;   // pair of reduction indices (same group of four)
-  const int j = blockIdx.y;                                     // output column
-  if (k2 >= P) return;
+  const int j = blockIdx.y;                                     // output column (P of them; Kd reduction indices)
+  if (k2 >= Kd) return;
   const float x0 = c * Bt[(size_t)j * ldb + k2], x1 = c * Bt[(size_t)j * ldb + k2 + 1];
   unsigned H, L;
   x2_split2(x0, x1, s, H, L);
@@ -132,10 +132,11 @@ __global__ void fx_split_b_kernel(FxSplitBatch sb, int ldb, int P, float c) {
   *reinterpret_cast<unsigned*>(Fx + base + (size_t)NB * 512) = L;
 }
 int64_t fused_b_image_floats(int P) { return (int64_t)P * P; }   // 2 planes of fp16 = 4 bytes per weight
-hipError_t launch_fx_split_b_batch(hipStream_t s, const FxSplitBatch& sb, int nb, int ldb, int P, float c) {
-  if ((P & 31) || nb < 1 || nb > FX_SPLIT_MAXB || !(c > 0.f)) return hipErrorInvalidValue;
-  dim3 grid((unsigned)((P / 2 + 127) / 128), (unsigned)P, (unsigned)nb);
-  hipLaunchKernelGGL(fx_split_b_kernel, grid, dim3(128), 0, s, sb, ldb, P, c);
+hipError_t launch_fx_split_b_batch(hipStream_t s, const FxSplitBatch& sb, int nb, int ldb, int P, float c, int Kd) {
+  if (Kd <= 0) Kd = P;                                     // square hidden layers by default
+  if ((P & 15) || (Kd & 31) || nb < 1 || nb > FX_SPLIT_MAXB || !(c > 0.f)) return hipErrorInvalidValue;
+  dim3 grid((unsigned)((Kd / 2 + 127) / 128), (unsigned)P, (unsigned)nb);
+  hipLaunchKernelGGL(fx_split_b_kernel, grid, dim3(128), 0, s, sb, ldb, P, Kd, c);
   return hipGetLastError();
 }
 
@@ -244,7 +245,7 @@ WIRE_DEVINL void fx_part(const FusedFwdParams& fp, const FxCtx& c, const f32x4 (
       }
       vv = f32x4{0.f, 0.f, 0.f, 0.f};
     } else {
-      const float* bl = c.sbias + (l_src - 1) * P + 64 * G + 16 * b + 4 * c.g;
+      const float* bl = c.sbias + l_src * P + 64 * G + 16 * b + 4 * c.g;
       const f32x4 b_re = *reinterpret_cast<const f32x4*>(bl), b_im = *reinterpret_cast<const f32x4*>(bl + 32);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -272,7 +273,7 @@ WIRE_DEVINL void fx_part(const FusedFwdParams& fp, const FxCtx& c, const f32x4 (
         for (int e = 0; e < 4; ++e) lin[e] = __builtin_fmaf(c.x[d], wd[e], lin[e]);
       }
     } else {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(c.sbias + (l_src - 1) * P + col);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(c.sbias + l_src * P + col);
 #pragma unroll
       for (int e = 0; e < 4; ++e) lin[e] = __builtin_fmaf(src[q][e], c.inv_prev, bv[e]);
     }
@@ -326,7 +327,7 @@ WIRE_DEVINL int fx_slice(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)[
         }
         w[0] = uu; w[1] = f32x4{0.f, 0.f, 0.f, 0.f};
       } else {
-        const float* bl = c.sbias + (l_src - 1) * P + 64 * G + 16 * b + 4 * c.g;
+        const float* bl = c.sbias + l_src * P + 64 * G + 16 * b + 4 * c.g;
         const f32x4 b_re = *reinterpret_cast<const f32x4*>(bl), b_im = *reinterpret_cast<const f32x4*>(bl + 32);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -391,7 +392,7 @@ WIRE_DEVINL int fx_slice(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)[
         }
         w[0] = lin;
       } else {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(c.sbias + (l_src - 1) * P + col);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(c.sbias + l_src * P + col);
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[0][e] = __builtin_fmaf(src[q][e], c.inv_prev, bv[e]);
       }
@@ -548,7 +549,7 @@ WIRE_DEVINL void fx_tail_train(const FusedFwdParams& fp, FxCtx& c, const f32x4 (
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb) {
     const int col = 16 * cb + 4 * c.g;
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(c.sbias + (fp.L - 1) * P + col);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(c.sbias + fp.L * P + col);
     f32x4 r;
 #pragma unroll
     for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(src[cb][e], c.inv_prev, bv[e]);
@@ -567,6 +568,65 @@ WIRE_DEVINL void fx_tail_train(const FusedFwdParams& fp, FxCtx& c, const f32x4 (
   }
   (void)CPLX;
   if (out && fp.amax_out) wire_amax_publish(fp.amax_out + (size_t)fp.L * WIRE_AMAX_SLOTS, amx, c.lane);
+}
+
+// layer 0 of a positional-encoding net (modules/relu.py:62-75 + :28-29) as a GEMM layer: the 64 padded input features
+// [c, {sin(2^i pi c_j), cos(2^i pi c_j)}] of this lane's row are evaluated in the lane (posenc_kernel's arithmetic), in the
+// order the two stages' k slots want them; dst = features W_0^T with the weight scale still on it
+template <int NB, int RING, int ABL>
+WIRE_DEVINL void fx_layer_pe(const FusedFwdParams& fp, FxCtx& c, f32x4 (&dst)[NB]) {
+  constexpr int STAGE = NB * 2048;
+  fx_u32x4 Fh[2], Fl[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 32 * j + (e < 4 ? 4 * c.g + e : 16 + 4 * c.g + (e - 4));
+      float x = 0.f;
+      if (k < fp.D) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) x = k == d ? c.x[d] : x;
+      } else if (k < fp.D + 2 * fp.D * fp.pe_F) {
+        const int ee = k - fp.D;
+        const int i = ee / (2 * fp.D), jj = (ee % (2 * fp.D)) >> 1;
+        float cj = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) cj = jj == d ? c.x[d] : cj;
+        const float freq = (float)((double)(1 << i) * 3.14159265358979323846);
+        float sn, cs;
+        wire_sincos(freq * cj, sn, cs);
+        x = (ee & 1) ? cs : sn;
+      }
+      v[e] = x;
+    }
+    unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+    fx_split2(v[0], v[1], h0, l0); fx_split2(v[2], v[3], h1, l1);
+    fx_split2(v[4], v[5], h2, l2); fx_split2(v[6], v[7], h3, l3);
+    Fh[j] = fx_u32x4{h0, h1, h2, h3};
+    Fl[j] = fx_u32x4{l0, l1, l2, l3};
+  }
+  float sB, invB;
+  fx_weight_scales(fp.wamax0, c.lane, 1.f, sB, invB);
+  (void)sB;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    fx_stage_top<NB, RING, ABL>(fp, c, 0);
+    const unsigned char* Sb = c.ring + c.buf * STAGE + c.lane * 16;
+    const fx_f16x8 ah = __builtin_bit_cast(fx_f16x8, Fh[j]), al = __builtin_bit_cast(fx_f16x8, Fl[j]);
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      const fx_f16x8 xh = *reinterpret_cast<const fx_f16x8*>(Sb + cb * 1024);
+      const fx_f16x8 xl = *reinterpret_cast<const fx_f16x8*>(Sb + (NB + cb) * 1024);
+      if (j == 0) dst[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, ah, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      else FX_MFMA(xl, ah, dst[cb]);
+      FX_MFMA(xh, al, dst[cb]);
+      FX_MFMA(xh, ah, dst[cb]);
+    }
+    c.t += 1;
+    c.buf = c.buf + 1 == RING ? 0 : c.buf + 1;
+  }
+  c.inv_prev = invB;
 }
 
 // final linear layer on h_L = act(accumulators of layer L): y[o] = sum_c h_L[c] wf[o][c] + bf[o]
@@ -609,10 +669,10 @@ WIRE_DEVINL void fx_final(const FusedFwdParams& fp, const FxCtx& c, const f32x4 
 
 template <int NB, int RING>
 constexpr int fx_lds_bytes() {
-  return RING * NB * 2048 + (4 * 16 * NB + 16 * NB + FX_LMAX * 16 * NB + 4 * 16 * NB) * 4;   // (first layer sized for PF = P)
+  return RING * NB * 2048 + (4 * 16 * NB + 16 * NB + (FX_LMAX + 1) * 16 * NB + 4 * 16 * NB) * 4;   // (first layer sized for PF = P)
 }
 
-template <int KIND, int NB, int RING, int ABL = 0, int TRAIN = 0>
+template <int KIND, int NB, int RING, int ABL = 0, int TRAIN = 0, bool PE = false>
 __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwdParams fp) {
   constexpr bool CPLX = FxKind<KIND>::CPLX;
   constexpr int P = 16 * NB, PF = CPLX ? P / 2 : P, S = NB / 2, STAGE = NB * 2048;
@@ -621,7 +681,7 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwd
   float* const sW0 = reinterpret_cast<float*>(fx_smem + RING * STAGE);
   float* const sb0 = sW0 + 4 * P;
   float* const sbias = sb0 + P;
-  float* const swf = sbias + FX_LMAX * P;
+  float* const swf = sbias + (FX_LMAX + 1) * P;
   const int tid = threadIdx.x;
   FxCtx c;
   c.lane = tid & 63;
@@ -631,7 +691,7 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwd
   c.row = (long long)blockIdx.x * FX_ROWS + c.wave * 16 + (c.lane & 15);
   c.ring = fx_smem;
   c.sW0 = sW0; c.sb0 = sb0; c.sbias = sbias; c.swf = swf;
-  c.t = 0; c.T = fp.L * S; c.buf = 0;
+  c.t = 0; c.T = fp.L * S + (PE ? 2 : 0); c.buf = 0;
   c.inv_prev = 1.f;
   c.st_lin = nullptr; c.st_out = nullptr; c.st_split = false; c.st_inv_c = 1.f; c.amx = 0.f; c.ys = 0;
   // the weight stream starts first: it does not depend on anything below
@@ -642,15 +702,19 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwd
 #pragma unroll
     for (int d = 0; d < 4; ++d) c.x[d] = d < fp.D ? fp.coords[rowc * fp.D + d] : 0.f;
   }
-  for (int i = tid; i < 4 * PF; i += 64 * FX_WAVES) {
-    const int d = i / PF, f = i - d * PF;
-    sW0[i] = (d < fp.D && f < fp.K) ? fp.c_first * fp.W0[f * fp.D + d] : 0.f;
+  if constexpr (!PE) {
+    for (int i = tid; i < 4 * PF; i += 64 * FX_WAVES) {
+      const int d = i / PF, f = i - d * PF;
+      sW0[i] = (d < fp.D && f < fp.K) ? fp.c_first * fp.W0[f * fp.D + d] : 0.f;
+    }
+    for (int i = tid; i < PF; i += 64 * FX_WAVES) sb0[i] = i < fp.K ? fp.c_first * fp.b0[i] : 0.f;
   }
-  for (int i = tid; i < PF; i += 64 * FX_WAVES) sb0[i] = i < fp.K ? fp.c_first * fp.b0[i] : 0.f;
-  for (int i = tid; i < fp.L * P; i += 64 * FX_WAVES) {
+  for (int i = tid; i < fp.L * P; i += 64 * FX_WAVES) {   // row l = layer l's bias, l = 1 .. L (row 0: a GEMM first layer's)
     const int l = i / P;
-    sbias[i] = fp.c_hidden * fp.bias[(size_t)l * fp.bias_stride + (i - l * P)];
+    sbias[P + i] = fp.c_hidden * fp.bias[(size_t)l * fp.bias_stride + (i - l * P)];
   }
+  if constexpr (PE)
+    for (int i = tid; i < P; i += 64 * FX_WAVES) sbias[i] = fp.bias0[i];
   if constexpr (!TRAIN) {                                // (the training forward ends at lin_L: no final layer here)
     for (int i = tid; i < fp.O * P; i += 64 * FX_WAVES) swf[i] = fp.wf[i];
   }
@@ -659,8 +723,15 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwd
   f32x4 accA[NB], accB[NB];
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb) accB[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  fx_layer<KIND, NB, RING, true, ABL, TRAIN>(fp, c, accB, accA, 1);
   int l = 2;
+  if constexpr (PE) {
+    // positional-encoding net: layer 0 is a GEMM over the 64 encoded features (two stages at the head of the weight stream),
+    // layer 1 then reads accumulators like every later one
+    fx_layer_pe<NB, RING, ABL>(fp, c, accA);
+    l = 1;
+  } else {
+    fx_layer<KIND, NB, RING, true, ABL, TRAIN>(fp, c, accB, accA, 1);
+  }
   for (; l + 1 <= fp.L; l += 2) {
     fx_layer<KIND, NB, RING, false, ABL, TRAIN>(fp, c, accA, accB, l);
     fx_layer<KIND, NB, RING, false, ABL, TRAIN>(fp, c, accB, accA, l + 1);
@@ -888,6 +959,16 @@ static hipError_t fx_launch_t(hipStream_t s, const FusedFwdParams& fp) {
         }
       }
       if (fp.rstore) return hipErrorInvalidValue;
+      if constexpr (KIND == NK_RELU && NB == 16) {
+        if (fp.pe_F > 0) {
+          const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_kernel<KIND, NB, RING, 0, 1, true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+          if (attr != hipSuccess) return attr;
+          hipLaunchKernelGGL((fused_fwd_kernel<KIND, NB, RING, 0, 1, true>), dim3(grid), dim3(64 * FX_WAVES), LDS, s, fp);
+          return hipGetLastError();
+        }
+      }
+      if (fp.pe_F > 0) return hipErrorInvalidValue;
       const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_kernel<KIND, NB, RING, 0, 1>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       if (attr != hipSuccess) return attr;
@@ -897,6 +978,16 @@ static hipError_t fx_launch_t(hipStream_t s, const FusedFwdParams& fp) {
       return hipErrorInvalidValue;
     }
   }
+  if constexpr (KIND == NK_RELU && NB == 16 && ABL == 0) {
+    if (fp.pe_F > 0) {
+      const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_kernel<KIND, NB, RING, 0, 0, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (attr != hipSuccess) return attr;
+      hipLaunchKernelGGL((fused_fwd_kernel<KIND, NB, RING, 0, 0, true>), dim3(grid), dim3(64 * FX_WAVES), LDS, s, fp);
+      return hipGetLastError();
+    }
+  }
+  if (fp.pe_F > 0) return hipErrorInvalidValue;
   const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_kernel<KIND, NB, RING, ABL>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (attr != hipSuccess) return attr;
@@ -910,6 +1001,8 @@ hipError_t launch_fused_fwd(hipStream_t s, int kind, int P, const FusedFwdParams
       fp.n > 0x7fffffffLL * FX_ROWS)
     return hipErrorInvalidValue;
   if (!(fp.c_first > 0.f) || !(fp.c_hidden > 0.f)) return hipErrorInvalidValue;
+  if (fp.pe_F > 0 && (kind != NK_RELU || !fp.bias0 || !fp.wamax0 || fp.D + 2 * fp.D * fp.pe_F > 64)) return hipErrorInvalidValue;
+  if (fp.pe_F == 0 && (!fp.W0 || !fp.b0)) return hipErrorInvalidValue;
   if (fp.out != nullptr && ((kind != NK_RELU && !fp.lin) || ((kind == NK_SIREN || kind == NK_GAUSS) && !fp.lin0) || !fp.amax_out))
     return hipErrorInvalidValue;
 #ifdef WIRE_FX_ABLATE

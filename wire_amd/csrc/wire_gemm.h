@@ -140,7 +140,7 @@ hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float*
 struct FxSplitBatch { const float* src[FX_SPLIT_MAXB]; void* dst[FX_SPLIT_MAXB]; const unsigned* slots[FX_SPLIT_MAXB]; };
 int64_t fused_b_image_floats(int P);                      // floats of one hidden layer's image
 // c: the constant folded into the weights (fused_pre_scale of the net kind and its omega_0 / scale_0)
-hipError_t launch_fx_split_b_batch(hipStream_t s, const FxSplitBatch& sb, int nb, int ldb, int P, float c);
+hipError_t launch_fx_split_b_batch(hipStream_t s, const FxSplitBatch& sb, int nb, int ldb, int P, float c, int Kd = 0);
 struct FusedFwdParams {
   const float* coords = nullptr; long long n = 0;         // [n][D]
   const float* W0 = nullptr; const float* b0 = nullptr;   // first layer, native [K][D], [K]
@@ -163,6 +163,9 @@ struct FusedFwdParams {
                                                           // pairs at scale 1 (relu: fp32, and out_L too)
   unsigned* amax_out = nullptr;                           // max |out_l| slots at amax_out + l * WIRE_AMAX_SLOTS (fp32-stored layers)
   float inv_c_first = 1.f, inv_c_hidden = 1.f;            // 1 / c: lin is stored in the reference's units
+  // positional-encoding nets (relu, modules/relu.py:62-75): pe_F > 0 frequencies -- layer 0 is a GEMM over the 64 padded
+  // encoded features, its image (P x 64, same format) lies in front of the hidden layers' at wimg, W0 / b0 are not read
+  int pe_F = 0; const float* bias0 = nullptr; const unsigned* wamax0 = nullptr;
   int rstore = 0;                                         // sine / Gaussian nets with the data-gradient chain: lin_1 .. lin_{L-1} are
                                                           // stored AS r = c lin and out_1 .. out_{L-1} not at all -- the chain and the
                                                           // weight-gradient loader (launch_gemmx2_tn, z_act) evaluate on r
