@@ -179,7 +179,7 @@ struct Plan {
   std::vector<int64_t> off_fwd, off_dg, off_bias, off_fwd_x3, off_dg_x3, off_fwd_3m, off_dg_3m, off_fwd_x2, off_dg_x2;
   int64_t off_wf, off_bf, off_first, off_wamax, total_packed;   // off_wamax: max-|weight| slots, WIRE_AMAX_SLOTS per layer
   int64_t off_fx;    // k-permuted 2 x fp16 images of the hidden layers for the fused forward (wire_fused.hip), -1 = no such shape
-  int64_t off_fxd;   // the same of the TRANSPOSED weights of layers L .. 2 (in that order) for the data-gradient chain, -1 = none
+  int64_t off_fxd;   // the same of the TRANSPOSED weights of layers L .. 1 (in that order) for the data-gradient chain, -1 = none
   std::vector<int64_t> tfloats;
 };
 
@@ -251,7 +251,7 @@ int make_plan(const wire_net_desc* d, Plan& p) {
   const bool fx_ok = p.L >= 1 && fused_fwd_shape(p.kind, p.P) && (!p.first_gemm || (p.kind == WIRE_KIND_RELU && p.Pin0 == 64));
   if (fx_ok) { p.off_fx = off; off += (p.first_gemm ? (int64_t)p.P * p.Pin0 : 0) + (int64_t)p.L * fused_b_image_floats(p.P); }
   p.off_fxd = -1;
-  if (fx_ok && p.L >= 2 && fused_bwd_shape(p.kind, p.P)) { p.off_fxd = off; off += (int64_t)(p.L - 1) * fused_b_image_floats(p.P); }
+  if (fx_ok && p.L >= 1 && fused_bwd_shape(p.kind, p.P)) { p.off_fxd = off; off += (int64_t)p.L * fused_b_image_floats(p.P); }
   p.off_wf = off; off += (int64_t)p.O * p.P;
   p.off_bf = off; off += 64;
   p.off_first = off;   // native copies of the first layer's tensors (W0,b0[,V0,c0])
@@ -334,7 +334,9 @@ ScratchLayout scratch_layout(const Plan& p, int64_t n) {
   s.fpw = off; off += (int64_t)nbf * p.O * p.P;
   s.fpb = off; off += (int64_t)nbf * p.O + 64;
   // (wire2d: two sets, one per Linear of the first layer, when the data-gradient epilogue forms the sums itself)
-  s.crp = off; off += (int64_t)(colreduce_blocks(n) + 32) * (p.cplx ? p.ldu : p.P) * 5 * (p.kind == WIRE_KIND_WIRE2D ? 2 : 1);
+  // (the data-gradient chain writes one block of first-layer sums per 64- or 128-row workgroup: 4 x the 256-row blocks)
+  s.crp = off; off += (int64_t)((p.off_fxd >= 0 ? 4 : 1) * colreduce_blocks(n) + 32) * (p.cplx ? p.ldu : p.P) * 5 *
+                      (p.kind == WIRE_KIND_WIRE2D ? 2 : 1);
   s.total = off;
   return s;
 }
@@ -371,7 +373,7 @@ bool fused_train_applies(const Plan& p, int64_t n) {
 // ... and its data gradients g_lin_L -> .. -> g_lin_1 as ONE kernel (the last link, layer 1 with the first layer's sums,
 // stays with the layer-by-layer kernel)
 bool fused_bwd_applies(const Plan& p, int64_t n) {
-  return fused_bwd_enabled() && p.off_fxd >= 0 && p.L >= 2 && fused_train_applies(p, n);
+  return fused_bwd_enabled() && p.off_fxd >= 0 && p.L >= 1 && fused_train_applies(p, n);
 }
 // ... and then the sine / Gaussian nets store NO inner out_l and their inner lin_l as r = c lin (the argument the activation
 // was evaluated on): the chain differentiates on r, the weight-gradient loader evaluates act(r) again -- 0.8 GB per step less
@@ -544,12 +546,11 @@ extern "C" int wire_pack_params(void* stream, const wire_net_desc* d, const void
         }
         HIPCHK(launch_fx_split_b_batch(s, fx, nb, p.P, p.P, fused_pre_scale(p.kind, p.w, p.s)));
       }
-      if (p.off_fxd >= 0) {                                // the data-gradient chain's: transposed images, layers L .. 2
+      if (p.off_fxd >= 0) {                                // the data-gradient chain's: transposed images, layers L .. 1
         FxSplitBatch fd{};
         int m = 0;
         for (int i = 0; i < nb; ++i) {
           const int l = l0 + i;
-          if (l < 2) continue;
           fd.src[m] = packed + p.off_dg[l];
           fd.dst[m] = packed + p.off_fxd + (int64_t)(p.L - l) * fused_b_image_floats(p.P);
           fd.slots[m] = ab.slots[i];
@@ -786,9 +787,11 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
                                             p.ldu));
   }
 
-  // ---- the data gradients of layers L .. 2 as one chain (wire_fused.hip): every g_lin_l lands in its own buffer, the
-  // weight-gradient GEMMs below read them, the layer-1 data gradient (first layer's sums) runs as before on g_lin_1
+  // ---- the data gradients of layers L .. 1 as one chain (wire_fused.hip): every g_lin_l (l >= 1) lands in its own buffer,
+  // the weight-gradient GEMMs below read them; the last link forms the first layer's sums g_lin_0^T [x | 1] per workgroup
+  // (positional encoding: stores g_lin_0 for the first layer's weight-gradient GEMM)
   const bool chain = !do_final && fused_bwd_applies(p, n);
+  int chain_rows = 0;
   if (chain) {
     FusedBwdParams bp;
     bp.n = n;
@@ -800,8 +803,11 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
     bp.wamax = reinterpret_cast<const unsigned*>(packed + p.off_wamax) + WIRE_AMAX_SLOTS; bp.wamax_stride = WIRE_AMAX_SLOTS;
     bp.L = p.L; bp.w = p.w; bp.s = p.s;
     bp.rstore = fused_rstore(p, n) ? 1 : 0; bp.c_hidden = fused_pre_scale(p.kind, p.w, p.s);
-    ProfScope ps(s, 1, 2.0 * n * p.Pl * p.P * (p.L - 1));
-    HIPCHK(launch_fused_bwd(s, p.kind, p.P, bp));
+    bp.aux0 = p.kind == WIRE_KIND_RELU ? A + a.out0 : A + a.lin0;
+    bp.w1 = p.w1;
+    if (!p.first_gemm) { bp.coords = coords; bp.D = p.D; bp.crp = Sx + sc.crp; bp.C = p.K; }
+    ProfScope ps(s, 1, 2.0 * n * p.Pl * p.P * p.L);
+    HIPCHK(launch_fused_bwd(s, p.kind, p.P, bp, &chain_rows));
   }
   // ---- hidden layers L..1
   for (int l = p.L; l >= 1; --l) {
@@ -869,7 +875,7 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
       if (p.per_layer == 4) { ep.W0b = packed + first_native_off(p, 2); ep.b0b = packed + first_native_off(p, 3); }
     }
     if (!p.cplx && l == 1) ep.ld0 = p.P;
-    if (chain && l >= 2) continue;                          // g_lin_{l-1} is already there
+    if (chain) continue;                                    // g_lin_{l-1} (l = 1: the first layer's sums) is already there
     { ProfScope ps(s, 1, 2.0 * n * p.Pl * p.P);
       if (x2) {
         ep.amax_a = gamax + l * WIRE_AMAX_SLOTS; ep.amax_b = wamax(l);
@@ -902,6 +908,9 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
       HIPCHK(launch_colreduce(s, gu + p.ldu, 2 * p.ldu, p.K, coords, p.D, n, Sx + sc.crp,
                               (float*)grads[2], (float*)grads[3]));
     }
+  } else if (!p.first_gemm && chain) {
+    HIPCHK(launch_colreduce_final_blocks(s, p.K, p.D, (int)((n + chain_rows - 1) / chain_rows), Sx + sc.crp, (float*)grads[0],
+                                         (float*)grads[1]));
   } else if (!p.first_gemm && first_sums_real) {
     HIPCHK(launch_colreduce_final(s, p.K, p.D, n, Sx + sc.crp, (float*)grads[0], (float*)grads[1]));
   } else if (!p.first_gemm) {
@@ -910,7 +919,7 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
     HIPCHK(launch_colreduce(s, g0, p.P, p.K, coords, p.D, n, Sx + sc.crp, (float*)grads[0],
                             (float*)grads[1]));
   } else {
-    const float* g0 = (p.L == 0) ? Sx + sc.ga : gcur;
+    const float* g0 = (p.L == 0) ? Sx + sc.ga : (chain ? Sx + sc.gch : gcur);   // the chain stored g_lin_0 in its slot 0
     const int S = p.x3 ? gemmx3_tn_splits(n, p.P, p.Pin0, sc.S) : gemm_tn_splits(n, p.P, p.Pin0, sc.S);
     if (p.x3)
       HIPCHK(launch_gemmx3_tn(s, g0, p.P, A + a.pe, p.Pin0, n, p.P, p.Pin0, S, Sx + sc.slab,

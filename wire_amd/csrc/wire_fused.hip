@@ -757,9 +757,21 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwd
 // of layer l - 1 reads it) with its maximum published for that GEMM's operand scale; lin_{l-1} (relu: out_{l-1}) is
 // prefetched into registers while the link's MFMAs run.  The scale of a link's operand is the wave's own maximum of the
 // g_lin it has just formed (gradients have no a-priori bound), so a link's epilogue is not pipelined under the next link's
-// MFMAs; the two waves of a SIMD overlap instead.  The last link (layer 1: the first layer's sums) stays with the
-// layer-by-layer kernel (wire_gemmh_epi.h, cr_partial).
+// MFMAs; the two waves of a SIMD overlap instead.  The last link (layer 1) differentiates through the FIRST layer's
+// activation (its own omega_0, lin_0 in the reference's units) and, for a native first layer, does not store g_lin_0: the
+// first layer's weight and bias gradient sums g_lin_0^T [x | 1] are formed from the accumulators (16 rows of a wave by DPP row
+// operations, the waves through LDS) and written per workgroup, as the layer-by-layer kernel's epilogue does per 256-row
+// tile (wire_gemmh_epi.h, cr_partial).
 // ---------------------------------------------------------------------------
+// sum over the 16 lanes of a DPP row (the 16 rows a wave holds of one column): quad_perm [1,0,3,2], [2,3,0,1],
+// row_half_mirror, row_mirror
+__device__ __forceinline__ float fx_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  return v;
+}
 template <int KIND, int NB, int RING, int W>
 __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwdParams fp) {
   constexpr int ACT = FxKind<KIND>::ACT;
@@ -774,7 +786,7 @@ __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwd
   c.n = fp.n;
   c.row = (long long)blockIdx.x * (16 * W) + c.wave * 16 + (c.lane & 15);
   c.ring = fx_smem;
-  const int links = fp.L - 1;                            // layers L .. 2
+  const int links = fp.L;                                // layers L .. 1
   c.t = 0; c.T = links * S; c.buf = 0;
   c.ys = 0;
   fx_issue<NB, RING, FusedBwdParams, W>(fp, c, 0, 0);
@@ -799,7 +811,8 @@ __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwd
   wire_x2_scales(wire_amax_read(fp.gamax + (size_t)fp.L * WIRE_AMAX_SLOTS, c.lane), sA, invA);
   fx_u32x4 Fh[S], Fl[S];
   int ys0 = 0, ys1 = 0;
-  for (int l = fp.L; l >= 2; --l) {
+  for (int l = fp.L; l >= 1; --l) {
+    const bool first = l == 1;                           // the link into the first layer
     // fragments of g_lin_l: blocks 2 j, 2 j + 1 of the lane's registers are stage j
 #pragma unroll
     for (int j = 0; j < S; ++j) {
@@ -814,7 +827,7 @@ __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwd
     // lin_{l-1} (relu: out_{l-1}) of this lane's 64 columns: in flight under the MFMAs below
     f32x4 aux[NB];
     {
-      const float* ap = fp.aux + (size_t)(l - 1) * fp.aux_stride + ro;
+      const float* ap = (first ? fp.aux0 : fp.aux + (size_t)(l - 1) * fp.aux_stride) + ro;
 #pragma unroll
       for (int cb = 0; cb < NB; ++cb) aux[cb] = *reinterpret_cast<const f32x4*>(ap + 16 * cb);
       ys0 += NB;
@@ -854,6 +867,16 @@ __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwd
     const float inv = invA * invB;
     float amx = 0.f;
     float* gp = fp.g + (size_t)(l - 1) * fp.g_stride + ro;
+    const bool rstore = fp.rstore && !first;             // lin_0 is stored in the reference's units
+    const float om = first ? fp.w1 : fp.w;
+    const bool sums = first && fp.crp != nullptr;
+    float xs[4] = {0.f, 0.f, 0.f, 0.f};
+    float* red = reinterpret_cast<float*>(fx_smem);      // [W waves][P columns][5]
+    if (sums) {
+      if (valid)
+        for (int d = 0; d < fp.D; ++d) xs[d] = fp.coords[(size_t)c.row * fp.D + d];
+      __syncthreads();                                   // every wave has read its last weight stage: the ring is free
+    }
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
       f32x4 gl;
@@ -861,26 +884,57 @@ __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwd
       for (int e = 0; e < 4; ++e) {
         const float go = acc[cb][e] * inv;
         float v;
-        if (fp.rstore && ACT == ACT_SIREN) {
+        if (rstore && ACT == ACT_SIREN) {
           // aux = r = omega lin / 2 pi: d sin(omega lin) / d lin = omega cos(2 pi r)
           v = go * fp.w * __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(aux[cb][e]));
-        } else if (fp.rstore && ACT == ACT_GAUSS) {
+        } else if (rstore && ACT == ACT_GAUSS) {
           // aux = r = s sqrt(log2 e) lin: out = exp2(-r^2), d out / d lin = -2 s^2 lin out = -(2 s^2 / c) r out
           const float r = aux[cb][e];
           v = go * __builtin_amdgcn_exp2f(-(r * r)) * (-2.f * fp.s * fp.s / fp.c_hidden) * r;
         } else {
           float out = 0.f;
-          if (ACT == ACT_GAUSS) out = real_act_fwd_lean<ACT_GAUSS>(aux[cb][e], fp.w, fp.s);
+          if (ACT == ACT_GAUSS) out = real_act_fwd_lean<ACT_GAUSS>(aux[cb][e], om, fp.s);
           if (ACT == ACT_RELU) out = aux[cb][e];
-          v = real_act_bwd_lean<ACT>(go, aux[cb][e], out, fp.w, fp.s);
+          v = real_act_bwd_lean<ACT>(go, aux[cb][e], out, om, fp.s);
         }
         gl[e] = valid ? v : 0.f;
         amx = __builtin_fmaxf(amx, __builtin_fabsf(gl[e]));
       }
-      *reinterpret_cast<f32x4*>(gp + 16 * cb) = gl;
+      if (sums) {
+        // g_lin_0^T [x | 1] of the wave's 16 rows; lane r = 0 of each column group holds the sum
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float* rp = red + ((size_t)c.wave * P + 16 * cb + 4 * c.g + e) * 5;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            if (d < fp.D) {
+              const float sv = fx_row16_sum(gl[e] * xs[d]);
+              if ((c.lane & 15) == 0) rp[d] = sv;
+            }
+          }
+          const float sv = fx_row16_sum(gl[e]);
+          if ((c.lane & 15) == 0) rp[4] = sv;
+        }
+      } else {
+        *reinterpret_cast<f32x4*>(gp + 16 * cb) = gl;
+      }
       acc[cb] = gl;
     }
+    if (sums) {
+      __syncthreads();
+      for (int e = tid; e < P * 5; e += 64 * W) {
+        const int col = e / 5, d = e - 5 * col;
+        float v = 0.f;
+        if (d < fp.D || d == 4) {
+#pragma unroll
+          for (int w = 0; w < W; ++w) v += red[(size_t)w * P * 5 + e];
+        }
+        if (col < fp.C) fp.crp[((size_t)blockIdx.x * fp.C + col) * 5 + d] = v;
+      }
+      return;                                            // (first is the last link)
+    }
     ys0 += NB;
+    if (first) return;
     // the next link's operand scale from this wave's maximum; the tensor's maximum for the weight-gradient GEMM
 #pragma unroll
     for (int o = 32; o; o >>= 1) amx = __builtin_fmaxf(amx, __shfl_xor(amx, o));
@@ -1055,17 +1109,22 @@ static hipError_t fxb_launch_w(hipStream_t s, const FusedBwdParams& fp) {
   return hipGetLastError();
 }
 template <int KIND>
-static hipError_t fxb_launch_t(hipStream_t s, const FusedBwdParams& fp) {
-  return g_fused_bwd_w == 8 ? fxb_launch_w<KIND, 8>(s, fp) : fxb_launch_w<KIND, 4>(s, fp);
+static hipError_t fxb_launch_t(hipStream_t s, const FusedBwdParams& fp, int W) {
+  return W == 8 ? fxb_launch_w<KIND, 8>(s, fp) : fxb_launch_w<KIND, 4>(s, fp);
 }
-hipError_t launch_fused_bwd(hipStream_t s, int kind, int P, const FusedBwdParams& fp) {
-  if (fp.n <= 0 || fp.L < 2) return hipSuccess;
-  if (!fused_bwd_shape(kind, P) || fp.L > FX_LMAX || !fp.g || !fp.aux || !fp.gamax || !fp.wamax || !fp.wimg)
+// *tile_rows: rows per workgroup of this launch = rows per block of fp.crp
+hipError_t launch_fused_bwd(hipStream_t s, int kind, int P, const FusedBwdParams& fp, int* tile_rows) {
+  const int W = g_fused_bwd_w;
+  if (tile_rows) *tile_rows = 16 * W;
+  if (fp.n <= 0 || fp.L < 1) return hipSuccess;
+  if (!fused_bwd_shape(kind, P) || fp.L > FX_LMAX || !fp.g || !fp.aux0 || (fp.L >= 2 && !fp.aux) || !fp.gamax || !fp.wamax ||
+      !fp.wimg)
     return hipErrorInvalidValue;
+  if (fp.crp && (!fp.coords || fp.D < 1 || fp.D > 4 || fp.C < 1 || fp.C > P)) return hipErrorInvalidValue;
   switch (kind) {
-    case NK_SIREN: return fxb_launch_t<NK_SIREN>(s, fp);
-    case NK_GAUSS: return fxb_launch_t<NK_GAUSS>(s, fp);
-    case NK_RELU: return fxb_launch_t<NK_RELU>(s, fp);
+    case NK_SIREN: return fxb_launch_t<NK_SIREN>(s, fp, W);
+    case NK_GAUSS: return fxb_launch_t<NK_GAUSS>(s, fp, W);
+    case NK_RELU: return fxb_launch_t<NK_RELU>(s, fp, W);
     default: return hipErrorInvalidValue;
   }
 }

@@ -185,12 +185,19 @@ struct FusedBwdParams {
                                                           // read, g_lin_{L-1} .. g_lin_1 are written (buffers padded to 128 rows)
   unsigned* gamax = nullptr;                              // max |g_lin_l| slots at gamax + l * WIRE_AMAX_SLOTS (L: read; below: written)
   const float* aux = nullptr; long long aux_stride = 0;   // lin_l (relu: out_l) at aux + l * aux_stride, l = 1 .. L - 1
-  const unsigned char* wimg = nullptr;                    // k-permuted images of the TRANSPOSED weights, layers L, L - 1, .. 2 back to back
+  const float* aux0 = nullptr;                            // lin_0 (relu: out_0) in the reference's units, rows of P floats
+  const unsigned char* wimg = nullptr;                    // k-permuted images of the TRANSPOSED weights, layers L, L - 1, .. 1 back to back
   const unsigned* wamax = nullptr; int wamax_stride = 0;  // max |W_l| slots of layer l at wamax + (l - 1) * wamax_stride
   int L = 0;
   float w = 0.f, s = 0.f;                                 // hidden omega_0, scale_0
   int rstore = 0; float c_hidden = 1.f;                   // aux holds r = c lin (FusedFwdParams::rstore), c
+  // the last link (layer 1): g_lin_0 = g_out_0 act'(lin_0) with the FIRST layer's omega_0.  crp != null (native first layer):
+  // g_lin_0 is not stored, its sums with [x | 1] per workgroup go to crp[blockIdx][C][5] (launch_colreduce_final_blocks adds
+  // them up: the first layer's weight and bias gradient); crp == null (positional encoding): g_lin_0 is stored at g + 0
+  float w1 = 0.f;
+  const float* coords = nullptr; int D = 0;
+  float* crp = nullptr; int C = 0;
 };
 bool fused_bwd_enabled();
 bool fused_bwd_shape(int kind, int P);
-hipError_t launch_fused_bwd(hipStream_t s, int kind, int P, const FusedBwdParams& fp);
+hipError_t launch_fused_bwd(hipStream_t s, int kind, int P, const FusedBwdParams& fp, int* tile_rows);

@@ -64,6 +64,7 @@ hipError_t launch_wgrad_reduce(hipStream_t s, int kind, const float* slab, const
 int colreduce_blocks(int64_t n);
 // partial must have room for (colreduce_blocks(n) + 32) * C * 5 floats
 hipError_t launch_colreduce_final(hipStream_t s, int C, int D, int64_t n, float* partial, float* gW0, float* gb0);
+hipError_t launch_colreduce_final_blocks(hipStream_t s, int C, int D, int nblk, float* partial, float* gW0, float* gb0);
 hipError_t launch_colreduce(hipStream_t s, const float* G, int ldg, int C, const float* x, int D,
                             int64_t n, float* partial, float* gW0, float* gb0);
 

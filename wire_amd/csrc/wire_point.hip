@@ -1047,8 +1047,12 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __res
 // stage 2 alone: partial[colreduce_blocks(n)][C][5] already holds the per-256-row sums (written by the data-gradient
 // epilogue of wire_gemmx3h.hip, GemmEpiParams::cr_partial)
 hipError_t launch_colreduce_final(hipStream_t s, int C, int D, int64_t n, float* partial, float* gW0, float* gb0) {
-  if (D > 4) return hipErrorInvalidValue;
-  const int nblk = colreduce_blocks(n);
+  return launch_colreduce_final_blocks(s, C, D, colreduce_blocks(n), partial, gW0, gb0);
+}
+// the same over nblk blocks of any row count (the data-gradient chain of wire_fused.hip writes one per workgroup); partial
+// must have room for (nblk + 32) * C * 5 floats
+hipError_t launch_colreduce_final_blocks(hipStream_t s, int C, int D, int nblk, float* partial, float* gW0, float* gb0) {
+  if (D > 4 || nblk < 1) return hipErrorInvalidValue;
   float* p2 = partial + (size_t)nblk * C * 5;            // slack reserved by colreduce_partial_floats
   const int nb = prereduce(s, partial, nblk, C * 5, p2);
   hipLaunchKernelGGL(colreduce_final_kernel, dim3(cdiv(C, 64)), dim3(256), 0, s, nb == nblk ? partial : p2, nb,
