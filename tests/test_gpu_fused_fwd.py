@@ -112,13 +112,19 @@ TRAIN_CASES = {
 }
 
 
-@pytest.mark.parametrize("case", list(TRAIN_CASES))
-def test_fused_training_forward_vs_layerwise_and_fp64_oracle(case):
+FINAL_CASES = ["siren_4x256", "gauss_3x256", "relu_4x256", "siren_1x256", "relu_posenc_3x256"]
+
+
+@pytest.mark.parametrize("case,final", [(c, 0) for c in TRAIN_CASES] + [(c, 1) for c in FINAL_CASES])
+def test_fused_training_forward_vs_layerwise_and_fp64_oracle(case, final):
     """The TRAINING forward as one kernel (knob "fused_train"): FusedTrainer.step stores lin_l / out_l from inside
     fused_fwd_kernel -- lin in the reference's units, out_0 fp32 + its maximum, the inner out_l as unscaled fp16 pairs (relu:
     fp32 + maxima) -- and the unchanged final stage, data-gradient and weight-gradient kernels read them.  Loss, output and
     every gradient against the layer-by-layer forward ("fused_train" = 0) and the fp64 oracle; ragged row count (the
-    kernel stores whole 128-row tiles: the padding rows of the act buffer take the overhang)."""
+    kernel stores whole 128-row tiles: the padding rows of the act buffer take the overhang).
+
+    final = 1: knob "fused_final" -- the real nets' final linear layer, MSE terms, dL/dy, g_lin_L and the final layer's
+    gradient sums formed in the tail of the same kernel (fx_tail_loss; not the default: measured no faster)."""
     from _util import oracle_grads_chunked
     from wire_amd import _lib
     from wire_amd.modules import models
@@ -128,15 +134,17 @@ def test_fused_training_forward_vs_layerwise_and_fp64_oracle(case):
     kind = kw["nonlin"]
     L = _lib.lib()
     assert L.wire_tune_get(b"fused_train") == 1
+    was_final = L.wire_tune_get(b"fused_final")
+    _lib.check(L.wire_tune_set(b"fused_final", final))
     grid = (131, 97)                                     # 12 707 rows: 99 workgroups and 35 rows
     N = grid[0] * grid[1]
     g = torch.Generator().manual_seed(9)
     target = torch.rand(N, 3, generator=g)
     perm = torch.randperm(N, generator=g)
     res = {}
-    for knob in (1, 0):
-        _lib.check(L.wire_tune_set(b"fused_train", knob))
-        try:
+    try:
+        for knob in (1, 0):
+            _lib.check(L.wire_tune_set(b"fused_train", knob))
             torch.manual_seed(6)
             model = models.get_INR(in_features=2, out_features=3, hidden_layers=Ln, **kw).to(DEV)
             tr = FusedTrainer(model, grid, target, lr=0.0, keep_rec=True)
@@ -144,8 +152,9 @@ def test_fused_training_forward_vs_layerwise_and_fp64_oracle(case):
             torch.cuda.synchronize()
             res[knob] = (float(loss.item()), tr.flat_grad.cpu().numpy().copy(), tr.rec.cpu().numpy()[perm.numpy()].copy())
             offsets = list(tr.offsets)
-        finally:
-            _lib.check(L.wire_tune_set(b"fused_train", 1))
+    finally:
+        _lib.check(L.wire_tune_set(b"fused_train", 1))
+        _lib.check(L.wire_tune_set(b"fused_final", was_final))
     assert not np.array_equal(res[0][1], res[1][1]), "the knob did not switch kernels"
     P = params_np(model)
     coords = wo.image_coords(*grid)[perm.numpy()]

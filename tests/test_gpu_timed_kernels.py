@@ -432,6 +432,31 @@ def test_fused_trainer_step_every_kind_vs_fp64_oracle_at_bench_size(case):
     perm = torch.randperm(N, generator=g)
     three_d = len(grid) == 3
     tr = FusedTrainer(model, grid, target, lr=0.0, keep_rec=True, coords_style="numpy" if three_d else "torch")
+    masks = None
+    if kind == "relu":
+        # relu's gradient is discontinuous at lin = 0: an element whose lin is round-off gets g_out from one correct fp32
+        # implementation and 0 from another, and ONE such element moves a 262 144-row gradient sum by 4e-6 of its maximum.
+        # As in the per-layer test (test_real_layers_identical_inputs_at_timed_shape) the comparison runs on identical
+        # decisions: the build's own (out_l > 0, read back from its activation buffer) are imposed on both oracles; the
+        # decisions that differ from the fp64 oracle's must be few and all at |lin| = round-off.
+        # With the final stage inside the forward kernel (knob "fused_final" = 1, not the default) no out_L is stored: the
+        # decisions of layer L are read from a step with the knob off -- the SAME kernel instantiation up to its tail, i.e.
+        # the same accumulator bits (lr = 0: the weights do not move between the two steps)
+        from wire_amd import _lib
+        Lh = _lib.lib()
+        was = Lh.wire_tune_get(b"fused_final")
+        _lib.check(Lh.wire_tune_set(b"fused_final", 0))
+        try:
+            tr.step(perm.to(DEV))
+            torch.cuda.synchronize()
+        finally:
+            _lib.check(Lh.wire_tune_set(b"fused_final", was))
+        act = tr.act.view(torch.float32)
+        K = model._arch["width"]
+        masks = []
+        for l in range(Ln + 1):
+            off = _lib.check(Lh.wire_act_out_offset(C.byref(tr.desc), N, l))
+            masks.append((act[off:off + N * K].view(N, K) > 0).cpu().numpy())
     loss = tr.step(perm.to(DEV))
     torch.cuda.synchronize()
     P = params_np(model)
@@ -441,20 +466,6 @@ def test_fused_trainer_step_every_kind_vs_fp64_oracle_at_bench_size(case):
     om = kw.get("hidden_omega_0", 30.0)
     sc = kw.get("scale", 10.0)
     nf = wo.posenc_num_frequencies(Dn, kw["sidelength"]) if kw.get("pos_encode") else None
-    masks = None
-    if kind == "relu":
-        # relu's gradient is discontinuous at lin = 0: an element whose lin is round-off gets g_out from one correct fp32
-        # implementation and 0 from another, and ONE such element moves a 262 144-row gradient sum by 4e-6 of its maximum.
-        # As in the per-layer test (test_real_layers_identical_inputs_at_timed_shape) the comparison runs on identical
-        # decisions: the build's own (out_l > 0, read back from its activation buffer) are imposed on both oracles; the
-        # decisions that differ from the fp64 oracle's must be few and all at |lin| = round-off.
-        from wire_amd import _lib
-        act = tr.act.view(torch.float32)
-        K = model._arch["width"]
-        masks = []
-        for l in range(Ln + 1):
-            off = _lib.check(_lib.lib().wire_act_out_offset(C.byref(tr.desc), N, l))
-            masks.append((act[off:off + N * K].view(N, K) > 0).cpu().numpy())
     y64, l64, g64 = oracle_grads_chunked(kind, P, coords, tgt, Ln, om1, om, sc, True, nf, relu_masks=masks)
     y32, l32, g32 = oracle_grads_chunked(kind, P, coords, tgt, Ln, om1, om, sc, False, nf, relu_masks=masks)
     # wire2d at 1 048 576 rows (round 4): the fp32 yardstick's own error depends on ITS summation

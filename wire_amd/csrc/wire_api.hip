@@ -330,7 +330,8 @@ ScratchLayout scratch_layout(const Plan& p, int64_t n) {
     full = (int64_t)s_max * p.Pl;
     s.bslab = off; off += needb3 > full ? needb3 : full;
   }
-  const int nbf = final_bwd_blocks(n) + 32;            // + pre-reduction scratch
+  // + pre-reduction scratch; the training forward with the final stage inside writes one block per 128-row workgroup
+  const int nbf = (p.off_fx >= 0 && !p.cplx ? 2 : 1) * final_bwd_blocks(n) + 32;
   s.fpw = off; off += (int64_t)nbf * p.O * p.P;
   s.fpb = off; off += (int64_t)nbf * p.O + 64;
   // (wire2d: two sets, one per Linear of the first layer, when the data-gradient epilogue forms the sums itself)
@@ -575,7 +576,7 @@ extern "C" int wire_pack_params(void* stream, const wire_net_desc* d, const void
 // ---------------------------------------------------------------------------
 static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const float* coords, int64_t n,
                         float* y, void* act, int64_t act_bytes, int save_for_bwd, bool do_final,
-                        bool skip_last_out = false) {
+                        bool skip_last_out = false, const FusedFwdParams* loss = nullptr, bool* loss_done = nullptr) {
   if (n < 0) return fail(WIRE_ERR_ARG, "negative n");
   if (n == 0) return WIRE_OK;
   if (!packed || !coords || (do_final && !y) || !act) return fail(WIRE_ERR_ARG, "null pointer");
@@ -641,6 +642,14 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
     fp.out = A + a.out0; fp.out_stride = a.np * p.P;
     fp.amax_out = amax;
     fp.rstore = fused_rstore(p, n) ? 1 : 0;
+    if (loss && loss_done && !p.cplx && fused_final_enabled()) {
+      // the final stage inside this kernel (wire_fused.hip: fx_tail_loss): lin_L / out_L are not stored at all
+      fp.wf = packed + p.off_wf; fp.bfr = packed + p.off_bf;
+      fp.target = loss->target; fp.idx = loss->idx; fp.first = loss->first; fp.gscale = loss->gscale;
+      fp.y = loss->y; fp.rec = loss->rec; fp.g_lin = loss->g_lin; fp.part_w = loss->part_w; fp.part_b = loss->part_b;
+      fp.loss_partial = loss->loss_partial; fp.amax_g = loss->amax_g;
+      *loss_done = true;
+    }
     ProfScope ps(s, 0, 2.0 * n * p.Pl * p.P * p.L);
     HIPCHK(launch_fused_fwd(s, p.kind, p.P, fp));
     return WIRE_OK;
@@ -720,7 +729,7 @@ extern "C" int wire_mlp_fwd(void* stream, const wire_net_desc* d, const float* p
 static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const float* coords, int64_t n,
                         const float* g_y, const void* act, int64_t act_bytes, void* scratch,
                         int64_t scratch_bytes, void* const* grads, bool do_final,
-                        wire_grad_ready_fn ready = nullptr, void* user = nullptr) {
+                        wire_grad_ready_fn ready = nullptr, void* user = nullptr, int final_blocks = 0) {
   if (n <= 0) return fail(WIRE_ERR_ARG, "backward needs n > 0");
   if (!packed || !coords || (do_final && !g_y) || !act || !scratch || !grads) return fail(WIRE_ERR_ARG, "null pointer");
   for (int i = 0; i < p.ntens; ++i) if (!grads[i]) return fail(WIRE_ERR_ARG, "grads[%d] is null", i);
@@ -750,7 +759,8 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
                                gemmx3_nt_is_h16(epi_bwd(p.kind), n);
 
   // ---- final linear + activation gradient of layer L
-  const int nbf = final_bwd_blocks(n);
+  // (final_blocks: the training forward formed the final layer's partial sums itself, one block per workgroup)
+  const int nbf = final_blocks > 0 ? final_blocks : final_bwd_blocks(n);
   if (!do_final) {
     ProfScope ps(s, 3, 0);
     HIPCHK(launch_final_reduce(s, p.kind, Sx + sc.fpw, Sx + sc.fpb, nbf, p.O, p.K, p.P,
@@ -968,21 +978,36 @@ extern "C" int wire_train_fwd_bwd_hooked(void* stream, const wire_net_desc* d, c
   // with layer L on the 16 x 16 x 32 forward kernel (lean epilogue) the final stage evaluates out_L from lin_L itself,
   // bit for bit what that epilogue would have stored: out_L is neither written nor read (1 GB less HBM traffic)
   const bool recomp = g_recompute_out && p.x3 && p.kind != WIRE_KIND_RELU && gemmx3_nt_is_h16(epi_fwd(p.kind), n);
-  if (int rc = mlp_fwd_core(stream, p, packed, coords, n, nullptr, act, act_bytes, 1, false, recomp)) return rc;
   const ActLayout a = act_layout(p, n, 1);
   const ScratchLayout sc = scratch_layout(p, n);
-  if (scratch_bytes < sc.total * 4) return fail(WIRE_ERR_SIZE, "scratch too small");
+  if (!scratch || scratch_bytes < sc.total * 4) return fail(WIRE_ERR_SIZE, "scratch too small");
   const float* A = (const float*)act;
   float* Sx = (float*)scratch;
+  const bool x2 = use_x2(p, n);
+  unsigned* const gamax = reinterpret_cast<unsigned*>(Sx + sc.gamax);
+  if (x2) HIPCHK(hipMemsetAsync(gamax, 0, (size_t)(p.L + 2) * WIRE_AMAX_SLOTS * sizeof(unsigned), s));
+  float* gL = fused_bwd_applies(p, n) ? Sx + sc.gch + (int64_t)p.L * sc.gch_stride : Sx + sc.ga;
+  // real nets on the whole-net training kernel: the final stage runs inside it (fx_tail_loss)
+  FusedFwdParams lp;
+  const int fblocks = (int)((n + 127) / 128);
+  const double inv_no = 1.0 / ((double)n * (double)p.O);
+  lp.target = target; lp.idx = idx; lp.first = first; lp.gscale = (float)(weight * 2.0 * inv_no);
+  lp.y = y; lp.rec = rec; lp.g_lin = gL; lp.part_w = Sx + sc.fpw; lp.part_b = Sx + sc.fpb; lp.loss_partial = Sx + sc.crp;
+  lp.amax_g = gamax + p.L * WIRE_AMAX_SLOTS;
+  bool loss_done = false;
+  if (int rc = mlp_fwd_core(stream, p, packed, coords, n, nullptr, act, act_bytes, 1, false, recomp,
+                            x2 && fused_bwd_applies(p, n) ? &lp : nullptr, &loss_done)) return rc;
+  if (loss_done) {
+    { ProfScope ps(s, 3, 0);
+      HIPCHK(launch_mse_final(s, Sx + sc.crp, fblocks, (float)(weight * inv_no), loss_out)); }
+    return mlp_bwd_core(stream, p, packed, coords, n, nullptr, act, act_bytes, scratch, scratch_bytes, grads, false, ready,
+                        user, fblocks);
+  }
   {
     // final linear forward + MSE (loss, rec) + final linear backward + Gabor gradient of layer L:
     // one pass over out_L / lin_L instead of three
     ProfScope ps(s, 3, 0);
     const float* linL = p.kind == WIRE_KIND_RELU ? nullptr : A + a.lin1 + (int64_t)(p.L - 1) * a.np * p.Pl;
-    const bool x2 = use_x2(p, n);
-    unsigned* const gamax = reinterpret_cast<unsigned*>(Sx + sc.gamax);
-    if (x2) HIPCHK(hipMemsetAsync(gamax, 0, (size_t)(p.L + 2) * WIRE_AMAX_SLOTS * sizeof(unsigned), s));
-    float* gL = fused_bwd_applies(p, n) ? Sx + sc.gch + (int64_t)p.L * sc.gch_stride : Sx + sc.ga;
     HIPCHK(launch_final_fused(s, p.kind, recomp ? nullptr : A + a.out0 + (int64_t)p.L * a.np * p.P, linL, n, p.P, p.O,
                               p.K, packed + p.off_wf, packed + p.off_bf, target, idx, first, weight,
                               p.w, p.s, y, rec, gL, Sx + sc.fpw, Sx + sc.fpb, Sx + sc.crp, loss_out,

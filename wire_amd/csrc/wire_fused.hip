@@ -160,6 +160,7 @@ struct FxCtx {
   const float* sb0;           // LDS: first layer bias [PF]
   const float* sbias;         // LDS: hidden biases [L][P] (GEMM column order)
   const float* swf;           // LDS: final image [4][P]
+  const long long* ssrc;      // LDS: source index of the workgroup's rows (final stage inside the training forward)
   int t, T, buf;              // weight stream: next stage to consume, number of stages, its ring buffer
   float inv_prev;             // 1 / (s_A s_B) of the accumulators in the source set
   // training forward: where the layer in production (l_src) is stored -- row pointers of THIS lane (row * P applied)
@@ -570,6 +571,152 @@ WIRE_DEVINL void fx_tail_train(const FusedFwdParams& fp, FxCtx& c, const f32x4 (
   if (out && fp.amax_out) wire_amax_publish(fp.amax_out + (size_t)fp.L * WIRE_AMAX_SLOTS, amx, c.lane);
 }
 
+// sums over the 16 lanes of a DPP row (the 16 rows a wave holds of one column) by quad_perm [1,0,3,2], [2,3,0,1],
+// row_half_mirror, row_mirror: every lane ends with the total.  N independent values, one butterfly step of all of them at a
+// time (a DPP operand wants two wait states after the instruction that wrote it: N chains side by side hide them)
+#define FX_DPP_ADD(v, ctrl) \
+  ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true)))
+template <int N>
+__device__ __forceinline__ void fx_row16_sum_n(float (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = FX_DPP_ADD(v[i], 0xB1);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = FX_DPP_ADD(v[i], 0x4E);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = FX_DPP_ADD(v[i], 0x141);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = FX_DPP_ADD(v[i], 0x140);
+}
+
+// training forward of a real net with the FINAL STAGE inside (fp.target != null): final linear layer, MSE terms, dL/dy, the
+// final layer's gradient sums and g_lin_L from the accumulators of layer L (modules/siren.py:84-88, gauss.py:64-69,
+// relu.py:112-118 forward; the MSE of wire_image_denoise.py:152 and autograd's backward of both).  Neither lin_L nor out_L
+// is stored; the arithmetic is final_fused_kernel's with act / act' evaluated on r = c lin
+template <int KIND, int NB>
+WIRE_DEVINL void fx_tail_loss(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)[NB]) {
+  constexpr int ACT = FxKind<KIND>::ACT;
+  constexpr int P = 16 * NB;
+  static_assert(!FxKind<KIND>::CPLX, "real nets");
+  const bool valid = c.row < c.n;
+  const int r16 = c.lane & 15;
+  const long long srow = c.ssrc[c.wave * 16 + r16];
+  float tg[4] = {0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+      if (o < fp.O) tg[o] = fp.target[srow * fp.O + o];
+  }
+  f32x4 rr[NB], oo[NB];
+  float yo[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) {
+    const int col = 16 * cb + 4 * c.g;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(c.sbias + fp.L * P + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      rr[cb][e] = __builtin_fmaf(src[cb][e], c.inv_prev, bv[e]);
+      oo[cb][e] = fx_act<ACT>(rr[cb][e]);
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      if (o < fp.O) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(c.swf + o * P + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yo[o] = __builtin_fmaf(oo[cb][e], wv[e], yo[o]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    yo[o] += __shfl_xor(yo[o], 16);
+    yo[o] += __shfl_xor(yo[o], 32);
+  }
+  float gy[4], lsum = 0.f;
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    gy[o] = 0.f;
+    if (o < fp.O) {
+      const float yy = yo[o] + fp.bfr[o];
+      const float dlt = valid ? yy - tg[o] : 0.f;
+      gy[o] = fp.gscale * dlt;
+      lsum = __builtin_fmaf(dlt, dlt, lsum);
+      if (c.g == o && valid) {
+        fp.y[c.row * fp.O + o] = yy;
+        if (fp.rec) fp.rec[srow * fp.O + o] = yy;
+      }
+    }
+  }
+  __syncthreads();                                       // every wave has read its last weight stage: the ring is free
+  float* red = reinterpret_cast<float*>(c.ring);         // [waves][O][P], then [waves][8]
+  float* red2 = red + FX_WAVES * 4 * P;
+  float amx = 0.f;
+  float* gp = fp.g_lin + (size_t)c.row * P;
+  const float dk = ACT == ACT_GAUSS ? -2.f * fp.s * fp.s / fp.c_hidden : fp.w;
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) {
+    const int col = 16 * cb + 4 * c.g;
+    f32x4 go = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      if (o < fp.O) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(c.swf + o * P + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) go[e] = __builtin_fmaf(gy[o], wv[e], go[e]);
+      }
+    }
+    f32x4 gl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float r = rr[cb][e];
+      float v;
+      if (ACT == ACT_SIREN) v = go[e] * dk * __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(r));   // omega cos(omega lin)
+      else if (ACT == ACT_GAUSS) v = go[e] * oo[cb][e] * dk * r;                                   // -2 s^2 lin out
+      else v = r > 0.f ? go[e] : 0.f;
+      gl[e] = v;
+      amx = __builtin_fmaxf(amx, __builtin_fabsf(v));
+    }
+    *reinterpret_cast<f32x4*>(gp + col) = gl;
+    // dL/dy^T h_L of the wave's 16 rows: every lane of a DPP row ends with the sum, lane r = 0 stores it
+    float sv[16];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sv[4 * o + e] = gy[o] * oo[cb][e];
+    fx_row16_sum_n<16>(sv);
+    if (r16 == 0) {
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (o < fp.O)
+          *reinterpret_cast<f32x4*>(red + ((size_t)c.wave * fp.O + o) * P + col) =
+              f32x4{sv[4 * o], sv[4 * o + 1], sv[4 * o + 2], sv[4 * o + 3]};
+    }
+  }
+  {
+    float sv[5] = {gy[0], gy[1], gy[2], gy[3], lsum};
+    fx_row16_sum_n<5>(sv);
+    if (c.lane == 0) {
+#pragma unroll
+      for (int o = 0; o < 5; ++o) red2[c.wave * 8 + o] = sv[o];
+    }
+  }
+  __syncthreads();
+  const int tid = c.wave * 64 + c.lane;
+  for (int e = tid; e < fp.O * P; e += 64 * FX_WAVES) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < FX_WAVES; ++w) v += red[(size_t)w * fp.O * P + e];
+    fp.part_w[(size_t)blockIdx.x * fp.O * P + e] = v;
+  }
+  if (tid < 5) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < FX_WAVES; ++w) v += red2[w * 8 + tid];
+    if (tid < fp.O) fp.part_b[(size_t)blockIdx.x * fp.O + tid] = v;
+    if (tid == 4) fp.loss_partial[blockIdx.x] = v;
+  }
+  wire_amax_publish(fp.amax_g, amx, c.lane);
+}
+
 // layer 0 of a positional-encoding net (modules/relu.py:62-75 + :28-29) as a GEMM layer: the 64 padded input features
 // [c, {sin(2^i pi c_j), cos(2^i pi c_j)}] of this lane's row are evaluated in the lane (posenc_kernel's arithmetic), in the
 // order the two stages' k slots want them; dst = features W_0^T with the weight scale still on it
@@ -669,7 +816,8 @@ WIRE_DEVINL void fx_final(const FusedFwdParams& fp, const FxCtx& c, const f32x4 
 
 template <int NB, int RING>
 constexpr int fx_lds_bytes() {
-  return RING * NB * 2048 + (4 * 16 * NB + 16 * NB + (FX_LMAX + 1) * 16 * NB + 4 * 16 * NB) * 4;   // (first layer sized for PF = P)
+  return RING * NB * 2048 + (4 * 16 * NB + 16 * NB + (FX_LMAX + 1) * 16 * NB + 4 * 16 * NB) * 4 +   // (first layer sized for PF = P)
+         FX_ROWS * 8;                                     // source indices of the rows (final stage inside the training forward)
 }
 
 template <int KIND, int NB, int RING, int ABL = 0, int TRAIN = 0, bool PE = false>
@@ -682,6 +830,7 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwd
   float* const sb0 = sW0 + 4 * P;
   float* const sbias = sb0 + P;
   float* const swf = sbias + (FX_LMAX + 1) * P;
+  long long* const ssrc = reinterpret_cast<long long*>(swf + 4 * P);
   const int tid = threadIdx.x;
   FxCtx c;
   c.lane = tid & 63;
@@ -690,7 +839,7 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwd
   c.n = fp.n;
   c.row = (long long)blockIdx.x * FX_ROWS + c.wave * 16 + (c.lane & 15);
   c.ring = fx_smem;
-  c.sW0 = sW0; c.sb0 = sb0; c.sbias = sbias; c.swf = swf;
+  c.sW0 = sW0; c.sb0 = sb0; c.sbias = sbias; c.swf = swf; c.ssrc = ssrc;
   c.t = 0; c.T = fp.L * S + (PE ? 2 : 0); c.buf = 0;
   c.inv_prev = 1.f;
   c.st_lin = nullptr; c.st_out = nullptr; c.st_split = false; c.st_inv_c = 1.f; c.amx = 0.f; c.ys = 0;
@@ -715,8 +864,16 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwd
   }
   if constexpr (PE)
     for (int i = tid; i < P; i += 64 * FX_WAVES) sbias[i] = fp.bias0[i];
-  if constexpr (!TRAIN) {                                // (the training forward ends at lin_L: no final layer here)
+  if (!TRAIN || fp.target) {                             // (the training forward without the final stage ends at lin_L)
     for (int i = tid; i < fp.O * P; i += 64 * FX_WAVES) swf[i] = fp.wf[i];
+  }
+  if constexpr (TRAIN != 0 && !CPLX) {
+    if (fp.target) {
+      for (int i = tid; i < FX_ROWS; i += 64 * FX_WAVES) {
+        const long long row = (long long)blockIdx.x * FX_ROWS + i;
+        ssrc[i] = row < fp.n ? (fp.idx ? (long long)fp.idx[row] : fp.first + row) : 0;
+      }
+    }
   }
   __syncthreads();
 
@@ -738,10 +895,16 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwd
   }
   if (l <= fp.L) {
     fx_layer<KIND, NB, RING, false, ABL, TRAIN>(fp, c, accA, accB, l);
-    if constexpr (TRAIN) fx_tail_train<KIND, NB>(fp, c, accB);
+    if constexpr (TRAIN != 0 && !CPLX) {
+      if (fp.target) fx_tail_loss<KIND, NB>(fp, c, accB);
+      else fx_tail_train<KIND, NB>(fp, c, accB);
+    } else if constexpr (TRAIN) fx_tail_train<KIND, NB>(fp, c, accB);
     else fx_final<KIND, NB>(fp, c, accB);
   } else {
-    if constexpr (TRAIN) fx_tail_train<KIND, NB>(fp, c, accA);
+    if constexpr (TRAIN != 0 && !CPLX) {
+      if (fp.target) fx_tail_loss<KIND, NB>(fp, c, accA);
+      else fx_tail_train<KIND, NB>(fp, c, accA);
+    } else if constexpr (TRAIN) fx_tail_train<KIND, NB>(fp, c, accA);
     else fx_final<KIND, NB>(fp, c, accA);
   }
 }
@@ -763,15 +926,6 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwd
 // operations, the waves through LDS) and written per workgroup, as the layer-by-layer kernel's epilogue does per 256-row
 // tile (wire_gemmh_epi.h, cr_partial).
 // ---------------------------------------------------------------------------
-// sum over the 16 lanes of a DPP row (the 16 rows a wave holds of one column): quad_perm [1,0,3,2], [2,3,0,1],
-// row_half_mirror, row_mirror
-__device__ __forceinline__ float fx_row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
-  return v;
-}
 template <int KIND, int NB, int RING, int W>
 __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwdParams fp) {
   constexpr int ACT = FxKind<KIND>::ACT;
@@ -901,19 +1055,20 @@ __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwd
         amx = __builtin_fmaxf(amx, __builtin_fabsf(gl[e]));
       }
       if (sums) {
-        // g_lin_0^T [x | 1] of the wave's 16 rows; lane r = 0 of each column group holds the sum
+        // g_lin_0^T [x | 1] of the wave's 16 rows: every lane of a DPP row ends with the sum, lane r = 0 stores it
+        float sv[20];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float* rp = red + ((size_t)c.wave * P + 16 * cb + 4 * c.g + e) * 5;
 #pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            if (d < fp.D) {
-              const float sv = fx_row16_sum(gl[e] * xs[d]);
-              if ((c.lane & 15) == 0) rp[d] = sv;
-            }
-          }
-          const float sv = fx_row16_sum(gl[e]);
-          if ((c.lane & 15) == 0) rp[4] = sv;
+          for (int d = 0; d < 4; ++d) sv[5 * e + d] = gl[e] * xs[d];
+          sv[5 * e + 4] = gl[e];
+        }
+        fx_row16_sum_n<20>(sv);
+        if ((c.lane & 15) == 0) {
+          float* rp = red + ((size_t)c.wave * P + 16 * cb + 4 * c.g) * 5;
+#pragma unroll
+          for (int q = 0; q < 5; ++q)
+            *reinterpret_cast<f32x4*>(rp + 4 * q) = f32x4{sv[4 * q], sv[4 * q + 1], sv[4 * q + 2], sv[4 * q + 3]};
         }
       } else {
         *reinterpret_cast<f32x4*>(gp + 16 * cb) = gl;
@@ -925,10 +1080,8 @@ __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwd
       for (int e = tid; e < P * 5; e += 64 * W) {
         const int col = e / 5, d = e - 5 * col;
         float v = 0.f;
-        if (d < fp.D || d == 4) {
 #pragma unroll
-          for (int w = 0; w < W; ++w) v += red[(size_t)w * P * 5 + e];
-        }
+        for (int w = 0; w < W; ++w) v += red[(size_t)w * P * 5 + e];
         if (col < fp.C) fp.crp[((size_t)blockIdx.x * fp.C + col) * 5 + d] = v;
       }
       return;                                            // (first is the last link)
@@ -962,6 +1115,13 @@ static std::atomic<int> g_fx_ablate{0};
 // "fused_train" / WIRE_FUSED_TRAIN: 1 (default) = training forwards of those nets run it too (storing lin_l / out_l)
 static std::atomic<int> g_fused_train{fx_env("WIRE_FUSED_TRAIN", 1)};
 bool fused_train_enabled() { return g_fused_train != 0 && g_fused_fwd != 0; }
+// "fused_final" / WIRE_FUSED_FINAL: 1 = wire_train_fwd_bwd of the real nets forms loss, dL/dy, g_lin_L and the final layer's
+// gradient sums inside the training forward (fx_tail_loss) instead of a pass over the stored lin_L / out_L.  Default 0:
+// measured neutral to slower (siren 2.05 / 2.03, gauss 2.02 / 1.94, relu 1.95 / 1.93 ms per step with / without,
+// profiles/r04_fused_final_ab.txt) -- the 0.18 ms pass it removes is HBM-bound and cheap, the tail it adds (3500 vector
+// instructions per wave, a third of them the 16-row sums of dL/dy^T h_L by DPP) runs with the matrix cores idle
+static std::atomic<int> g_fused_final{fx_env("WIRE_FUSED_FINAL", 0)};
+bool fused_final_enabled() { return g_fused_final != 0 && fused_train_enabled(); }
 int fused_bwd_knob();
 void fused_bwd_knob_set(int v);
 void fused_bwd_w_set(int v);
@@ -969,12 +1129,14 @@ int fused_tune_get(const char* key) {
   if (!strcmp(key, "fused_fwd")) return g_fused_fwd;
   if (!strcmp(key, "fused_train")) return g_fused_train;
   if (!strcmp(key, "fused_bwd")) return fused_bwd_knob();
+  if (!strcmp(key, "fused_final")) return g_fused_final;
   return -1;
 }
 int fused_tune_set(const char* key, int value) {
   if (!strcmp(key, "fused_fwd") && value >= 0 && value <= 1) { g_fused_fwd = value; return 0; }
   if (!strcmp(key, "fused_train") && value >= 0 && value <= 1) { g_fused_train = value; return 0; }
   if (!strcmp(key, "fused_bwd") && value >= 0 && value <= 1) { fused_bwd_knob_set(value); return 0; }
+  if (!strcmp(key, "fused_final") && value >= 0 && value <= 1) { g_fused_final = value; return 0; }
   if (!strcmp(key, "fused_bwd_w") && (value == 4 || value == 8)) { fused_bwd_w_set(value); return 0; }
 #ifdef WIRE_FX_ABLATE
   if (!strcmp(key, "fx_ablate") && value >= 0 && value <= 15) { g_fx_ablate = value; return 0; }
@@ -1058,6 +1220,9 @@ hipError_t launch_fused_fwd(hipStream_t s, int kind, int P, const FusedFwdParams
   if (fp.pe_F > 0 && (kind != NK_RELU || !fp.bias0 || !fp.wamax0 || fp.D + 2 * fp.D * fp.pe_F > 64)) return hipErrorInvalidValue;
   if (fp.pe_F == 0 && (!fp.W0 || !fp.b0)) return hipErrorInvalidValue;
   if (fp.out != nullptr && ((kind != NK_RELU && !fp.lin) || ((kind == NK_SIREN || kind == NK_GAUSS) && !fp.lin0) || !fp.amax_out))
+    return hipErrorInvalidValue;
+  if (fp.target != nullptr && (kind == NK_WIRE || !fp.out || !fp.wf || !fp.bfr || !fp.y || !fp.g_lin || !fp.part_w || !fp.part_b ||
+                               !fp.loss_partial || !fp.amax_g))
     return hipErrorInvalidValue;
 #ifdef WIRE_FX_ABLATE
   if (kind == NK_SIREN) {

@@ -169,7 +169,18 @@ struct FusedFwdParams {
   int rstore = 0;                                         // sine / Gaussian nets with the data-gradient chain: lin_1 .. lin_{L-1} are
                                                           // stored AS r = c lin and out_1 .. out_{L-1} not at all -- the chain and the
                                                           // weight-gradient loader (launch_gemmx2_tn, z_act) evaluate on r
+  // the final stage inside the training forward (real nets; target != null): from the accumulators of layer L the wave forms
+  // y = h_L W_f^T + b_f, the MSE terms against target[src] (src = idx ? idx[row] : first + row), dL/dy = gscale (y - t),
+  // g_lin_L = (dL/dy W_f) act'(lin_L) -- stored, its maximum published -- and per workgroup the sums dL/dy^T h_L, sum dL/dy,
+  // sum (y - t)^2 (what final_fused_kernel of wire_point.hip does from the stored lin_L / out_L, which are then not written)
+  const float* target = nullptr; const int64_t* idx = nullptr; long long first = 0; float gscale = 0.f;
+  float* rec = nullptr;                                   // optional scatter of y to rec[src]
+  float* g_lin = nullptr;                                 // g_lin_L rows of P floats (padded to 128 rows)
+  float* part_w = nullptr; float* part_b = nullptr;       // [block][O][P], [block][O]: launch_final_reduce adds them up
+  float* loss_partial = nullptr;                          // [block]
+  unsigned* amax_g = nullptr;                             // max |g_lin_L| slots
 };
+bool fused_final_enabled();
 bool fused_train_enabled();
 float fused_pre_scale(int kind, float omega0, float scale0);   // the c of a layer with these hyper-parameters
 bool fused_fwd_shape(int kind, int P);

@@ -106,6 +106,7 @@ hipError_t launch_perm_indices(hipStream_t s, uint64_t seed, int64_t n_total, in
 hipError_t launch_coords(hipStream_t s, const int64_t* idx, int64_t first, int64_t n,
                          const float* tx, int W, const float* ty, int H, const float* tz, int T,
                          float* coords);
+hipError_t launch_mse_final(hipStream_t s, const float* partial, int nb, float lscale, float* loss_out);
 hipError_t launch_mse_grad(hipStream_t s, const float* y, const float* target, const int64_t* idx,
                            int64_t first, int64_t n, int O, float weight, float* g_y,
                            float* loss_out, float* rec, float* partial);

@@ -1421,6 +1421,11 @@ __global__ void mse_final_kernel(const float* __restrict__ partial, int nb, floa
   }
   if (threadIdx.x == 0) loss_out[0] = red[0] * lscale;
 }
+// loss_out[0] = lscale * sum of nb partial sums (one block)
+hipError_t launch_mse_final(hipStream_t s, const float* partial, int nb, float lscale, float* loss_out) {
+  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, s, partial, nb, lscale, loss_out);
+  return hipGetLastError();
+}
 hipError_t launch_mse_grad(hipStream_t s, const float* y, const float* target, const int64_t* idx,
                            int64_t first, int64_t n, int O, float weight, float* g_y,
                            float* loss_out, float* rec, float* partial) {
