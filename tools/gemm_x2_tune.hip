@@ -202,6 +202,11 @@ int main(int argc, char** argv) {
       // ablation (results wrong): every row of A is row 0 -> all A loads hit the caches
       {"x2h store (LDS), A cached [abl]", 2, EPI_STORE, 0, 10}, {"x2h store (regs), A cached [abl]", 2, EPI_STORE, 0, 11},
   };
+  if (const char* only = getenv("X2_ONLY")) {            // keep the variants whose name contains this
+    std::vector<Var> keep;
+    for (const Var& v : vars) if (strstr(v.name, only)) keep.push_back(v);
+    vars.swap(keep);
+  }
   std::vector<double> best(vars.size(), 1e30), sum(vars.size(), 0);
   for (int r = 0; r < rounds + 1; ++r) {
     for (size_t v = 0; v < vars.size(); ++v) {

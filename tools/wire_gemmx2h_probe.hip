@@ -437,6 +437,17 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
         x2_split2(araw[rb][1][2], araw[rb][1][3], s_a, H[3], L[3]);
         ah[rb] = __builtin_bit_cast(f16x8, x2u32x4{H[0], H[1], H[2], H[3]});
         al[rb] = __builtin_bit_cast(f16x8, x2u32x4{L[0], L[1], L[2], L[3]});
+#ifdef X2_PROBE_3M
+        // timing probe (results wrong) of the 3-multiplication complex product on the split: the third operand a_re + a_im
+        // costs 4 adds + 2 more splits per 16-row block and stage (8 + 4 per stage pair) ...
+        {
+          const f32x4 sm = araw[rb][0] + araw[rb][1];
+          unsigned H2[2], L2[2];
+          x2_split2(sm[0], sm[1], s_a, H2[0], L2[0]);
+          x2_split2(sm[2], sm[3], s_a, H2[1], L2[1]);
+          asm volatile("" :: "v"(H2[0]), "v"(H2[1]), "v"(L2[0]), "v"(L2[1]));
+        }
+#endif
       }
     }
     if constexpr (AMODE == 1) {
@@ -494,6 +505,9 @@ __global__ __launch_bounds__(256, (NRB == 2 ? 3 : 2)) void gemmx2h_nt_kernel(con
       for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
         for (int cq = 0; cq < 4; ++cq) {
+#ifdef X2_PROBE_3M
+          if (cq == 3) continue;                           // ... and 9 instead of 12 MFMAs (and three instead of four weight planes)
+#endif
           // small terms first; operands swapped (weights first): the block comes out transposed, four consecutive
           // columns per lane (wire_gemmh_epi.h)
           X2_MFMA(bl[cq], ah[rb], acc[rb][4 * hb + cq]);
@@ -987,7 +1001,8 @@ static hipError_t launch_x2_tn_t(hipStream_t s, dim3 grid, const float* G, int l
 // z_pre_inv != 0: Z is a pre-split activation (wire_dev.h: wire_store_out4), 1 / its scale; amax_z is not read.
 hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n, int Pm,
                             int Pn, int splits, float* slab, float* bslab, const unsigned* amax_g,
-                            const unsigned* amax_z, float z_pre_inv) {
+                            const unsigned* amax_z, float z_pre_inv, int z_act) {
+  if (z_act != 0) return hipErrorInvalidValue;           // (round 4's activation-evaluating loader: product kernel only)
   const int shp = x2_tn_shape(Pm, Pn);
   if (!shp || (ldg & 3) || (ldz & 3) || splits < 1 || n < 1 || !amax_g || (!amax_z && z_pre_inv == 0.f))
     return hipErrorInvalidValue;
