@@ -181,3 +181,47 @@ def test_fused_training_forward_vs_layerwise_and_fp64_oracle(case, final):
             within_ref(relmax(mine, ref), max(relmax(ref32, ref), relmax(lay, ref)), f"fused_train[{case}] grad {name}")
         else:
             within_ref(relmax(mine, ref), relmax(ref32, ref), f"fused_train[{case}] grad {name}")
+
+
+@pytest.mark.parametrize("nonlin", ["siren", "relu"])
+def test_wgrad_batch_matches_per_layer_launches(nonlin):
+    """Behind the data-gradient chain the weight gradients of layers 2 .. L run as ONE launch of gemmx2_tn16_kernel (knob
+    "wgrad_batch", default 1: blockIdx.y = layer, operands a fixed step apart, each member accumulating L - 1 times the rows
+    into a third of the slabs).  Same products, another split of the row sum: every gradient agrees with the per-layer
+    launches to fp32 round-off of a 65 536-row sum, and the first layer's and the final layer's -- not touched -- bit for bit.
+    Autograd of the hidden Linear layers, modules/siren.py:48-49, relu.py:28-29."""
+    from wire_amd import _lib
+    from wire_amd.modules import models
+    from wire_amd.trainer import FusedTrainer
+    L = _lib.lib()
+    assert L.wire_tune_get(b"wgrad_batch") == 1
+    grid = (256, 256)
+    N = grid[0] * grid[1]
+    g = torch.Generator().manual_seed(3)
+    target = torch.rand(N, 3, generator=g)
+    perm = torch.randperm(N, generator=g)
+    res = {}
+    try:
+        for knob in (1, 0):
+            _lib.check(L.wire_tune_set(b"wgrad_batch", knob))
+            torch.manual_seed(8)
+            kw = dict(first_omega_0=30.0, hidden_omega_0=30.0) if nonlin == "siren" else {}
+            model = models.get_INR(nonlin=nonlin, in_features=2, out_features=3, hidden_features=256, hidden_layers=4, **kw).to(DEV)
+            tr = FusedTrainer(model, grid, target, lr=0.0)
+            tr.step(perm.to(DEV))
+            torch.cuda.synchronize()
+            res[knob] = tr.flat_grad.cpu().numpy().copy()
+            offsets, names = list(tr.offsets), [k for k in model.state_dict().keys() if "omega_0" not in k and "scale_0" not in k]
+    finally:
+        _lib.check(L.wire_tune_set(b"wgrad_batch", 1))
+    sizes = np.diff(offsets + [res[1].size])
+    switched = False
+    for name, off, sz in zip(names, offsets, sizes):
+        a, b = res[1][off:off + sz], res[0][off:off + sz]
+        layer = int(name.split(".")[1])
+        if 2 <= layer <= 4:
+            switched = switched or not np.array_equal(a, b)
+            assert relmax(a, b) <= 1e-5, f"{name}: {relmax(a, b):.3e}"
+        else:
+            assert np.array_equal(a, b), f"{name} moved although its kernels did not change"
+    assert switched, "the knob did not switch kernels"

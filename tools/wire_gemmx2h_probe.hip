@@ -1001,8 +1001,8 @@ static hipError_t launch_x2_tn_t(hipStream_t s, dim3 grid, const float* G, int l
 // z_pre_inv != 0: Z is a pre-split activation (wire_dev.h: wire_store_out4), 1 / its scale; amax_z is not read.
 hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n, int Pm,
                             int Pn, int splits, float* slab, float* bslab, const unsigned* amax_g,
-                            const unsigned* amax_z, float z_pre_inv, int z_act) {
-  if (z_act != 0) return hipErrorInvalidValue;           // (round 4's activation-evaluating loader: product kernel only)
+                            const unsigned* amax_z, float z_pre_inv, int z_act, int batch, long long, long long, int) {
+  if (z_act != 0 || batch != 1) return hipErrorInvalidValue;   // (round 4's activation-evaluating loader, batches: product kernel only)
   const int shp = x2_tn_shape(Pm, Pn);
   if (!shp || (ldg & 3) || (ldz & 3) || splits < 1 || n < 1 || !amax_g || (!amax_z && z_pre_inv == 0.f))
     return hipErrorInvalidValue;

@@ -128,6 +128,8 @@ static std::atomic<int> g_split_f16{env_flag("WIRE_SPLIT_F16", 1)};
 static std::atomic<int> g_split_out{env_flag("WIRE_SPLIT_OUT", 1)};
 // with the fused training forward + data-gradient chain of a sine / Gaussian net: store r = c lin and no out_l ("fused_rstore")
 static std::atomic<int> g_fused_rstore{env_flag("WIRE_FUSED_RSTORE", 1)};
+// behind the data-gradient chain: the weight gradients of layers 2 .. L as one launch ("wgrad_batch" / WIRE_WGRAD_BATCH)
+static std::atomic<int> g_wgrad_batch{env_flag("WIRE_WGRAD_BATCH", 1)};
 // family the flags select for a net kind (wire_layer_api.hip): 2 split-bf16, 1 complex 3M (wire only), 0 4M
 int wire_family_(int kind) {
   if (g_split_bf16) return 2;
@@ -140,6 +142,7 @@ extern "C" int wire_tune_get(const char* key) {
   if (!strcmp(key, "split_bf16")) return g_split_bf16;
   if (!strcmp(key, "split_out")) return g_split_out;
   if (!strcmp(key, "fused_rstore")) return g_fused_rstore;
+  if (!strcmp(key, "wgrad_batch")) return g_wgrad_batch;
   if (!strcmp(key, "x3_h16")) return gemmx3h_mode();
   if (!strcmp(key, "x3_tn16")) return gemmx3_tn16_mode();
   if (!strcmp(key, "recompute_out")) return g_recompute_out;
@@ -157,6 +160,7 @@ extern "C" int wire_tune_set(const char* key, int value) {
   if (!strcmp(key, "split_f16")) { g_split_f16 = value ? 1 : 0; return WIRE_OK; }
   if (!strcmp(key, "split_out")) { g_split_out = value ? 1 : 0; return WIRE_OK; }
   if (!strcmp(key, "fused_rstore")) { g_fused_rstore = value ? 1 : 0; return WIRE_OK; }
+  if (!strcmp(key, "wgrad_batch")) { g_wgrad_batch = value ? 1 : 0; return WIRE_OK; }
   if (gemmx2h_tune_set(key, value) == 0) return WIRE_OK;
   if (fused_tune_set(key, value) == 0) return WIRE_OK;
   if (gemm_tune_set(key, value) == 0) return WIRE_OK;
@@ -819,6 +823,24 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
     ProfScope ps(s, 1, 2.0 * n * p.Pl * p.P * p.L);
     HIPCHK(launch_fused_bwd(s, p.kind, p.P, bp, &chain_rows));
   }
+  // ---- behind the chain every g_lin_l exists before the first weight gradient starts: those of layers 2 .. L (same shape,
+  // operands a fixed step apart) run as ONE launch, each member accumulating L - 1 times the rows into a third of the slabs
+  int wbatch = 0, wbatch_S = 0;
+  if (chain && g_wgrad_batch && p.L >= 3 && x2 && gemmx2_tn_applies(p.Pl, p.P)) {
+    const int nb = p.L - 1;
+    const int S = gemmx2_tn_batch_splits(n, p.Pl, p.P, sc.S, nb);
+    if (S >= 1 && (int64_t)S * nb <= sc.S) {
+      const bool rs = fused_rstore(p, n);
+      const float s_z = rs ? 0.f : out_split_scale(p, n, 1);
+      ProfScope ps(s, 2, 2.0 * n * p.Pl * p.P * nb);
+      HIPCHK(launch_gemmx2_tn(s, Sx + sc.gch + 2 * sc.gch_stride, p.Pl, rs ? lin_l(1) : out_l(1), rs ? p.Pl : p.P, n, p.Pl, p.P,
+                              S, Sx + sc.slab, Sx + sc.bslab, gamax + 2 * WIRE_AMAX_SLOTS, amax + WIRE_AMAX_SLOTS,
+                              rs ? 1.f / 16384.f : (s_z != 0.f ? 1.f / s_z : 0.f),
+                              rs ? (p.kind == WIRE_KIND_SIREN ? 2 : 3) : 0, nb, sc.gch_stride,
+                              rs ? a.np * p.Pl : a.np * p.P, WIRE_AMAX_SLOTS));
+      wbatch = nb; wbatch_S = S;
+    }
+  }
   // ---- hidden layers L..1
   for (int l = p.L; l >= 1; --l) {
     if (chain) gcur = Sx + sc.gch + (int64_t)l * sc.gch_stride;
@@ -833,6 +855,12 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
                                 Sx + sc.bslab)); }
       ProfScope ps(s, 3, 0);
       HIPCHK(launch_wgrad3m_reduce(s, Sx + sc.slab, Sx + sc.bslab, S, p.K, p.K, p.Kp, p.Kp, gW, gb));
+      if (ready) ready(user, p.per_layer * l, p.per_layer);
+    } else if (wbatch > 0 && l >= 2) {
+      // the batch above wrote this layer's slabs: member l - 2
+      ProfScope ps(s, 3, 0);
+      HIPCHK(launch_wgrad_reduce(s, p.kind, Sx + sc.slab + (int64_t)(l - 2) * wbatch_S * p.Pl * p.P,
+                                 Sx + sc.bslab + (int64_t)(l - 2) * wbatch_S * p.Pl, wbatch_S, p.K, p.K, p.Pl, p.P, gW, gb, gV, gc));
       if (ready) ready(user, p.per_layer * l, p.per_layer);
     } else {
       const bool x2tn = x2 && gemmx2_tn_applies(p.Pl, p.P);

@@ -132,7 +132,9 @@ bool gemmx2_tn_applies(int Pm, int Pn);
 int gemmx2_tn_splits(int64_t n, int Pm, int Pn, int max_splits);
 hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n, int Pm,
                             int Pn, int splits, float* slab, float* bslab, const unsigned* amax_g,
-                            const unsigned* amax_z, float z_pre_inv = 0.f, int z_act = 0);
+                            const unsigned* amax_z, float z_pre_inv = 0.f, int z_act = 0, int batch = 1,
+                            long long g_step = 0, long long z_step = 0, int amax_step = 0);
+int gemmx2_tn_batch_splits(int64_t n, int Pm, int Pn, int max_splits, int batch);
 
 // ---- whole-net forward in one kernel (wire_fused.hip): activations stay in the wave's registers from the coordinates to
 // the output; the hidden layers' weights come from a k-permuted edition of the 2 x fp16 image (same maximum slots)

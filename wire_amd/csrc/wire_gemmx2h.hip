@@ -569,7 +569,19 @@ template <int WM, int WN, int ZMODE>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
     const float* __restrict__ G, int ldg, const float* __restrict__ Z, int ldz, long long n, int Pm, int Pn,
     int tiles_n, int nsplit, long long chunk, float* __restrict__ slab, float* __restrict__ bslab, int tiles,
-    const unsigned* __restrict__ amax_g, const unsigned* __restrict__ amax_z, const float z_pre_inv) {
+    const unsigned* __restrict__ amax_g, const unsigned* __restrict__ amax_z, const float z_pre_inv,
+    const long long g_step, const long long z_step, const int amax_step) {
+  // blockIdx.y = member of a BATCH of weight gradients of equal shape (the hidden layers behind the data-gradient chain of
+  // wire_fused.hip, whose g_lin_l / activations / maximum slots lie a fixed step apart): one launch fills the chip with
+  // nsplit x gridDim.y workgroups, each accumulating gridDim.y times the rows -- a third of the slabs at three layers
+  {
+    const int by = blockIdx.y;
+    G += (size_t)by * g_step; Z += (size_t)by * z_step;
+    slab += (size_t)by * nsplit * Pm * Pn;
+    if (bslab) bslab += (size_t)by * nsplit * Pm;
+    amax_g += by * amax_step;
+    if (amax_z) amax_z += by * amax_step;
+  }
   constexpr int NW = WM * WN;                       // waves
   constexpr int TM = 64 * WM, TN = 128 * WN;        // tile: features of G x features of Z
   constexpr int GPLANE = X2T_TK * TM * 2, ZPLANE = X2T_TK * TN * 2;   // bytes of one fp16 plane of a stage
@@ -858,10 +870,22 @@ int gemmx2_tn_splits(int64_t n, int Pm, int Pn, int max_splits) {
   return s < 1 ? 1 : s;
 }
 
+// row splits per member of a batch of `batch` weight gradients (launch_gemmx2_tn): the chip filled once by all members
+// together, and exactly as many splits as the launcher's 64-row rounding of the chunk will use
+int gemmx2_tn_batch_splits(int64_t n, int Pm, int Pn, int max_splits, int batch) {
+  int s = gemmx2_tn_splits(n, Pm, Pn, max_splits);
+  if (batch <= 1 || s < batch) return s;
+  s /= batch;
+  long long chunk = (n + s - 1) / s;
+  chunk = (chunk + 2 * X2T_TK - 1) / (2 * X2T_TK) * (2 * X2T_TK);
+  return (int)((n + chunk - 1) / chunk);
+}
+
 template <int WM, int WN, int ZMODE>
 static hipError_t launch_x2_tn_z(hipStream_t s, dim3 grid, const float* G, int ldg, const float* Z, int ldz, int64_t n,
                                  int Pm, int Pn, int tiles_n, int used, long long chunk, float* slab, float* bslab,
-                                 int tiles, const unsigned* amax_g, const unsigned* amax_z, float z_pre_inv) {
+                                 int tiles, const unsigned* amax_g, const unsigned* amax_z, float z_pre_inv,
+                                 long long g_step, long long z_step, int amax_step) {
   constexpr int STAGE = X2T_TK * (64 * WM + 128 * WN) * 4;
   // > 64 KB of dynamic LDS needs the opt-in; per launch (a host-side call of about a microsecond), because the attribute
   // belongs to the current device's copy of the function and a process may drive more than one
@@ -869,15 +893,17 @@ static hipError_t launch_x2_tn_z(hipStream_t s, dim3 grid, const float* G, int l
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
   if (attr != hipSuccess) return attr;
   hipLaunchKernelGGL((gemmx2_tn16_kernel<WM, WN, ZMODE>), grid, dim3(64 * WM * WN), 2 * STAGE, s, G, ldg, Z, ldz,
-                     (long long)n, Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles, amax_g, amax_z, z_pre_inv);
+                     (long long)n, Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles, amax_g, amax_z, z_pre_inv, g_step, z_step,
+                     amax_step);
   return hipGetLastError();
 }
 template <int WM, int WN>
 static hipError_t launch_x2_tn_t(hipStream_t s, dim3 grid, const float* G, int ldg, const float* Z, int ldz, int64_t n,
                                  int Pm, int Pn, int tiles_n, int used, long long chunk, float* slab, float* bslab,
-                                 int tiles, const unsigned* amax_g, const unsigned* amax_z, float z_pre_inv, int z_act) {
+                                 int tiles, const unsigned* amax_g, const unsigned* amax_z, float z_pre_inv, int z_act,
+                                 long long g_step, long long z_step, int amax_step) {
 #define X2_TN_Z(M) launch_x2_tn_z<WM, WN, M>(s, grid, G, ldg, Z, ldz, n, Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles, amax_g, \
-                                            amax_z, z_pre_inv)
+                                            amax_z, z_pre_inv, g_step, z_step, amax_step)
   if constexpr (WM == 4 && WN == 2) {                      // the re-evaluating loaders: the 256-feature real nets only
     if (z_act == 2) return X2_TN_Z(2);
     if (z_act == 3) return X2_TN_Z(3);
@@ -891,12 +917,15 @@ static hipError_t launch_x2_tn_t(hipStream_t s, dim3 grid, const float* G, int l
 // z_pre_inv != 0: Z is a pre-split activation (wire_dev.h: wire_store_out4), 1 / its scale; amax_z is not read.
 // z_act = 2 / 3: Z holds the pre-activation r of a sine / Gaussian layer as wire_fused.hip stored it; the loader evaluates the
 // activation again and splits with scale 1 / z_pre_inv (which must be given).
+// batch > 1: `batch` weight gradients of the same shape in one launch -- member j reads G + j g_step, Z + j z_step and the
+// maximum slots amax_g + j amax_step (amax_z likewise) and writes the slabs [j][splits][Pm][Pn] (+ bslab [j][splits][Pm]).
 hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float* Z, int ldz, int64_t n, int Pm,
                             int Pn, int splits, float* slab, float* bslab, const unsigned* amax_g,
-                            const unsigned* amax_z, float z_pre_inv, int z_act) {
+                            const unsigned* amax_z, float z_pre_inv, int z_act, int batch, long long g_step,
+                            long long z_step, int amax_step) {
   const int shp = x2_tn_shape(Pm, Pn);
   if (!shp || (ldg & 3) || (ldz & 3) || splits < 1 || n < 1 || !amax_g || (!amax_z && z_pre_inv == 0.f) ||
-      (z_act != 0 && (z_act < 2 || z_act > 3 || z_pre_inv == 0.f)))
+      (z_act != 0 && (z_act < 2 || z_act > 3 || z_pre_inv == 0.f)) || batch < 1 || batch > 8)
     return hipErrorInvalidValue;
   const int TMf = 64 * (shp / 10), TNf = 128 * (shp % 10);
   const int tiles_m = Pm / TMf, tiles_n = (Pn + TNf - 1) / TNf;
@@ -904,7 +933,9 @@ hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float*
   chunk = (chunk + 2 * X2T_TK - 1) / (2 * X2T_TK) * (2 * X2T_TK);
   const int used = (int)((n + chunk - 1) / chunk);
   const int splits_pad = (used + 7) & ~7;
-  dim3 grid((unsigned)(tiles_m * tiles_n * splits_pad));
+  dim3 grid((unsigned)(tiles_m * tiles_n * splits_pad), (unsigned)batch);
+  if (batch > 1 && used != splits) return hipErrorInvalidValue;   // (a batch's slab sets lie `used` slabs apart: ask for what
+                                                                  //  gemmx2_tn_batch_splits returns)
   if (used < splits) {   // slabs of unused splits must still be defined for the reduce kernels
     hipError_t e = hipMemsetAsync(slab + (size_t)used * Pm * Pn, 0, (size_t)(splits - used) * Pm * Pn * 4, s);
     if (e != hipSuccess) return e;
@@ -913,7 +944,7 @@ hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float*
       if (e != hipSuccess) return e;
     }
   }
-#define X2_TN_ARGS s, grid, G, ldg, Z, ldz, n, Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles_m * tiles_n, amax_g, amax_z, z_pre_inv, z_act
+#define X2_TN_ARGS s, grid, G, ldg, Z, ldz, n, Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles_m * tiles_n, amax_g, amax_z, z_pre_inv, z_act, g_step, z_step, amax_step
   switch (shp) {
     case 42: return launch_x2_tn_t<4, 2>(X2_TN_ARGS);
     case 61: return launch_x2_tn_t<6, 1>(X2_TN_ARGS);
