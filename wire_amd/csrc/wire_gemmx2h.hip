@@ -875,7 +875,13 @@ int gemmx2_tn_splits(int64_t n, int Pm, int Pn, int max_splits) {
 int gemmx2_tn_batch_splits(int64_t n, int Pm, int Pn, int max_splits, int batch) {
   int s = gemmx2_tn_splits(n, Pm, Pn, max_splits);
   if (batch <= 1 || s < batch) return s;
-  s /= batch;
+  // an XCD (32 CUs, one workgroup each) receives tiles x ceil(splits / 8) workgroups of EVERY member: 3 members x 11 = 33 ran
+  // one workgroup behind the others on four XCDs and the launch took twice as long (the first edition: + 0.1 ms per step)
+  const int shp = x2_tn_shape(Pm, Pn);
+  const int tiles = (Pm / (64 * (shp / 10))) * ((Pn + 128 * (shp % 10) - 1) / (128 * (shp % 10)));
+  const int groups = 32 / (tiles * batch);
+  if (groups < 1) return 0;
+  if (s > 8 * groups) s = 8 * groups;
   long long chunk = (n + s - 1) / s;
   chunk = (chunk + 2 * X2T_TK - 1) / (2 * X2T_TK) * (2 * X2T_TK);
   return (int)((n + chunk - 1) / chunk);
