@@ -825,20 +825,22 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
   }
   // ---- behind the chain every g_lin_l exists before the first weight gradient starts: those of layers 2 .. L (same shape,
   // operands a fixed step apart) run as ONE launch, each member accumulating L - 1 times the rows into a third of the slabs
-  int wbatch = 0, wbatch_S = 0;
-  if (chain && g_wgrad_batch && p.L >= 3 && x2 && gemmx2_tn_applies(p.Pl, p.P)) {
-    const int nb = p.L - 1;
-    const int S = gemmx2_tn_batch_splits(n, p.Pl, p.P, sc.S, nb);
+  // (layer 1 joins when its activation operand has the form of the others': r_0 of the sine / Gaussian nets, relu's fp32 out_0)
+  int wbatch = 0, wbatch_S = 0, wbatch_l0 = 2;
+  if (chain && g_wgrad_batch && x2 && gemmx2_tn_applies(p.Pl, p.P)) {
+    const bool rs = fused_rstore(p, n);
+    const int l0 = (rs || p.kind == WIRE_KIND_RELU) ? 1 : 2;
+    const int nb = p.L - l0 + 1;
+    const int S = nb >= 2 ? gemmx2_tn_batch_splits(n, p.Pl, p.P, sc.S, nb) : 0;
     if (S >= 1 && (int64_t)S * nb <= sc.S) {
-      const bool rs = fused_rstore(p, n);
-      const float s_z = rs ? 0.f : out_split_scale(p, n, 1);
+      const float s_z = rs ? 0.f : out_split_scale(p, n, l0);
       ProfScope ps(s, 2, 2.0 * n * p.Pl * p.P * nb);
-      HIPCHK(launch_gemmx2_tn(s, Sx + sc.gch + 2 * sc.gch_stride, p.Pl, rs ? lin_l(1) : out_l(1), rs ? p.Pl : p.P, n, p.Pl, p.P,
-                              S, Sx + sc.slab, Sx + sc.bslab, gamax + 2 * WIRE_AMAX_SLOTS, amax + WIRE_AMAX_SLOTS,
-                              rs ? 1.f / 16384.f : (s_z != 0.f ? 1.f / s_z : 0.f),
+      HIPCHK(launch_gemmx2_tn(s, Sx + sc.gch + l0 * sc.gch_stride, p.Pl, rs ? lin_l(l0 - 1) : out_l(l0 - 1), rs ? p.Pl : p.P, n,
+                              p.Pl, p.P, S, Sx + sc.slab, Sx + sc.bslab, gamax + l0 * WIRE_AMAX_SLOTS,
+                              amax + (l0 - 1) * WIRE_AMAX_SLOTS, rs ? 1.f / 16384.f : (s_z != 0.f ? 1.f / s_z : 0.f),
                               rs ? (p.kind == WIRE_KIND_SIREN ? 2 : 3) : 0, nb, sc.gch_stride,
                               rs ? a.np * p.Pl : a.np * p.P, WIRE_AMAX_SLOTS));
-      wbatch = nb; wbatch_S = S;
+      wbatch = nb; wbatch_S = S; wbatch_l0 = l0;
     }
   }
   // ---- hidden layers L..1
@@ -856,18 +858,19 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
       ProfScope ps(s, 3, 0);
       HIPCHK(launch_wgrad3m_reduce(s, Sx + sc.slab, Sx + sc.bslab, S, p.K, p.K, p.Kp, p.Kp, gW, gb));
       if (ready) ready(user, p.per_layer * l, p.per_layer);
-    } else if (wbatch > 0 && l >= 2) {
-      // the batch above wrote this layer's slabs: member l - 2
+    } else if (wbatch > 0 && l >= wbatch_l0) {
+      // the batch above wrote this layer's slabs: member l - l0
       ProfScope ps(s, 3, 0);
-      HIPCHK(launch_wgrad_reduce(s, p.kind, Sx + sc.slab + (int64_t)(l - 2) * wbatch_S * p.Pl * p.P,
-                                 Sx + sc.bslab + (int64_t)(l - 2) * wbatch_S * p.Pl, wbatch_S, p.K, p.K, p.Pl, p.P, gW, gb, gV, gc));
+      HIPCHK(launch_wgrad_reduce(s, p.kind, Sx + sc.slab + (int64_t)(l - wbatch_l0) * wbatch_S * p.Pl * p.P,
+                                 Sx + sc.bslab + (int64_t)(l - wbatch_l0) * wbatch_S * p.Pl, wbatch_S, p.K, p.K, p.Pl, p.P, gW, gb,
+                                 gV, gc));
       if (ready) ready(user, p.per_layer * l, p.per_layer);
     } else {
       const bool x2tn = x2 && gemmx2_tn_applies(p.Pl, p.P);
       const int S = x2tn ? gemmx2_tn_splits(n, p.Pl, p.P, sc.S)
                          : (p.x3 ? gemmx3_tn_splits(n, p.Pl, p.P, sc.S) : gemm_tn_splits(n, p.Pl, p.P, sc.S));
       { ProfScope ps(s, 2, 2.0 * n * p.Pl * p.P);
-        if (x2tn && chain && l >= 2 && fused_rstore(p, n)) {
+        if (x2tn && chain && fused_rstore(p, n)) {
           // Z = act(r_{l-1}) evaluated by the loader from the stored pre-activation (no out_{l-1} exists), scale 2^14
           HIPCHK(launch_gemmx2_tn(s, gcur, p.Pl, lin_l(l - 1), p.Pl, n, p.Pl, p.P, S, Sx + sc.slab, Sx + sc.bslab,
                                   gamax + l * WIRE_AMAX_SLOTS, nullptr, 1.f / 16384.f,

@@ -305,9 +305,9 @@ WIRE_DEVINL int fx_slice(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)[
   constexpr int P = 16 * NB, PF = CPLX ? P / 2 : P, NP = fx_nparts<KIND, NB>();
   // what a training forward stores of the layer in production (compile-time: the store count per stage is part of the
   // weight stream's wait): lin unless relu / wire's real layer 0; out fp32 for layer 0 and relu, else the split pairs
-  // (TRAIN = 2, sine / Gaussian nets whose backward is the chain: the inner layers store r itself and no out at all)
+  // (TRAIN = 2, sine / Gaussian nets whose backward is the chain: EVERY layer below L stores r itself and no out at all)
   constexpr bool ST_LIN = TRAIN && KIND != NK_RELU && (!FROM_COORDS || !CPLX);
-  constexpr bool ST_F32 = TRAIN && (KIND == NK_RELU || FROM_COORDS);
+  constexpr bool ST_F32 = TRAIN && (KIND == NK_RELU || (FROM_COORDS && TRAIN != 2));
   constexpr bool ST_SPLIT = TRAIN == 1 && !ST_F32;
   if constexpr (CPLX) {
     constexpr int ST = NB / 9;                            // block stride between steps
@@ -469,7 +469,7 @@ WIRE_DEVINL void fx_layer(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)
       c.st_lin = (FROM_COORDS ? fp.lin0 : fp.lin + (size_t)(ls - 1) * fp.lin_stride) + ro;
     c.st_out = fp.out + (size_t)ls * fp.out_stride + ro;
     c.st_split = KIND != NK_RELU && !FROM_COORDS;
-    c.st_inv_c = FROM_COORDS ? fp.inv_c_first : (TRAIN == 2 ? 1.f : fp.inv_c_hidden);
+    c.st_inv_c = TRAIN == 2 ? 1.f : (FROM_COORDS ? fp.inv_c_first : fp.inv_c_hidden);
     c.amx = 0.f;
   }
   float sA = 1.f, invA = 1.f;                          // (bounded activations are split unscaled)
@@ -534,7 +534,8 @@ WIRE_DEVINL void fx_layer(const FusedFwdParams& fp, FxCtx& c, const f32x4 (&src)
   c.inv_prev = invA * invB;
   if constexpr (TRAIN) {
     // max |out_{l-1}| of the fp32-stored activations for the GEMMs that read them as operands (weight gradient)
-    if (!c.st_split && fp.amax_out) wire_amax_publish(fp.amax_out + (size_t)(l - 1) * WIRE_AMAX_SLOTS, c.amx, c.lane);
+    if (!c.st_split && fp.amax_out && !(TRAIN == 2 && FROM_COORDS))
+      wire_amax_publish(fp.amax_out + (size_t)(l - 1) * WIRE_AMAX_SLOTS, c.amx, c.lane);
   }
 }
 
@@ -1021,7 +1022,7 @@ __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwd
     const float inv = invA * invB;
     float amx = 0.f;
     float* gp = fp.g + (size_t)(l - 1) * fp.g_stride + ro;
-    const bool rstore = fp.rstore && !first;             // lin_0 is stored in the reference's units
+    const bool rstore = fp.rstore != 0;                  // aux holds r = c lin (layer 0: c of the first omega_0)
     const float om = first ? fp.w1 : fp.w;
     const bool sums = first && fp.crp != nullptr;
     float xs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1040,7 +1041,7 @@ __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwd
         float v;
         if (rstore && ACT == ACT_SIREN) {
           // aux = r = omega lin / 2 pi: d sin(omega lin) / d lin = omega cos(2 pi r)
-          v = go * fp.w * __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(aux[cb][e]));
+          v = go * om * __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(aux[cb][e]));
         } else if (rstore && ACT == ACT_GAUSS) {
           // aux = r = s sqrt(log2 e) lin: out = exp2(-r^2), d out / d lin = -2 s^2 lin out = -(2 s^2 / c) r out
           const float r = aux[cb][e];

@@ -168,9 +168,9 @@ struct FusedFwdParams {
   // positional-encoding nets (relu, modules/relu.py:62-75): pe_F > 0 frequencies -- layer 0 is a GEMM over the 64 padded
   // encoded features, its image (P x 64, same format) lies in front of the hidden layers' at wimg, W0 / b0 are not read
   int pe_F = 0; const float* bias0 = nullptr; const unsigned* wamax0 = nullptr;
-  int rstore = 0;                                         // sine / Gaussian nets with the data-gradient chain: lin_1 .. lin_{L-1} are
-                                                          // stored AS r = c lin and out_1 .. out_{L-1} not at all -- the chain and the
-                                                          // weight-gradient loader (launch_gemmx2_tn, z_act) evaluate on r
+  int rstore = 0;                                         // sine / Gaussian nets with the data-gradient chain: lin_0 .. lin_{L-1} are
+                                                          // stored AS r = c lin (lin0, lin) and out_0 .. out_{L-1} not at all -- the
+                                                          // chain and the weight-gradient loader (launch_gemmx2_tn, z_act) evaluate on r
   // the final stage inside the training forward (real nets; target != null): from the accumulators of layer L the wave forms
   // y = h_L W_f^T + b_f, the MSE terms against target[src] (src = idx ? idx[row] : first + row), dL/dy = gscale (y - t),
   // g_lin_L = (dL/dy W_f) act'(lin_L) -- stored, its maximum published -- and per workgroup the sums dL/dy^T h_L, sum dL/dy,
@@ -198,7 +198,7 @@ struct FusedBwdParams {
                                                           // read, g_lin_{L-1} .. g_lin_1 are written (buffers padded to 128 rows)
   unsigned* gamax = nullptr;                              // max |g_lin_l| slots at gamax + l * WIRE_AMAX_SLOTS (L: read; below: written)
   const float* aux = nullptr; long long aux_stride = 0;   // lin_l (relu: out_l) at aux + l * aux_stride, l = 1 .. L - 1
-  const float* aux0 = nullptr;                            // lin_0 (relu: out_0) in the reference's units, rows of P floats
+  const float* aux0 = nullptr;                            // lin_0 (rstore: r_0 = c_first lin_0; relu: out_0), rows of P floats
   const unsigned char* wimg = nullptr;                    // k-permuted images of the TRANSPOSED weights, layers L, L - 1, .. 1 back to back
   const unsigned* wamax = nullptr; int wamax_stride = 0;  // max |W_l| slots of layer l at wamax + (l - 1) * wamax_stride
   int L = 0;
