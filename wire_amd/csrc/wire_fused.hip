@@ -927,7 +927,9 @@ __global__ __launch_bounds__(64 * FX_WAVES) void fused_fwd_kernel(const FusedFwd
 // operations, the waves through LDS) and written per workgroup, as the layer-by-layer kernel's epilogue does per 256-row
 // tile (wire_gemmh_epi.h, cr_partial).
 // ---------------------------------------------------------------------------
-template <int KIND, int NB, int RING, int W>
+// ABL (harness builds, -DWIRE_FX_ABLATE; results wrong): 1 no lin_{l-1} loads, 2 no g_lin stores, 4 no activation derivative,
+// 8 no MFMAs, 16 no stage barrier / weight wait, 32 no weight-fragment LDS reads, 64 no splits
+template <int KIND, int NB, int RING, int W, int ABL = 0>
 __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwdParams fp) {
   constexpr int ACT = FxKind<KIND>::ACT;
   constexpr int P = 16 * NB, S = NB / 2, STAGE = NB * 2048;
@@ -972,28 +974,43 @@ __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwd
 #pragma unroll
     for (int j = 0; j < S; ++j) {
       unsigned h0, l0, h1, l1, h2, l2, h3, l3;
-      x2_split2(acc[2 * j][0], acc[2 * j][1], sA, h0, l0);
-      x2_split2(acc[2 * j][2], acc[2 * j][3], sA, h1, l1);
-      x2_split2(acc[2 * j + 1][0], acc[2 * j + 1][1], sA, h2, l2);
-      x2_split2(acc[2 * j + 1][2], acc[2 * j + 1][3], sA, h3, l3);
+      if constexpr (ABL & 64) {
+        h0 = h1 = h2 = h3 = 0x3c003c00u; l0 = l1 = l2 = l3 = 0x14001400u;
+        asm volatile("" : "+v"(h0), "+v"(l0));
+      } else {
+        x2_split2(acc[2 * j][0], acc[2 * j][1], sA, h0, l0);
+        x2_split2(acc[2 * j][2], acc[2 * j][3], sA, h1, l1);
+        x2_split2(acc[2 * j + 1][0], acc[2 * j + 1][1], sA, h2, l2);
+        x2_split2(acc[2 * j + 1][2], acc[2 * j + 1][3], sA, h3, l3);
+      }
       Fh[j] = fx_u32x4{h0, h1, h2, h3};
       Fl[j] = fx_u32x4{l0, l1, l2, l3};
     }
-    // lin_{l-1} (relu: out_{l-1}) of this lane's 64 columns: in flight under the MFMAs below
+    // lin_{l-1} (relu: out_{l-1}) of this lane's 64 columns: in flight under the MFMAs below.  NOT all at the head of the link
+    // (the first edition): vector-memory operations complete in order, so the wait for the weight pieces of
+    // stage 2 -- issued after these loads -- was a wait for 16 KB of HBM reads per wave, and the link ran as "HBM time, then
+    // matrix-core time" (0.22 ms per link where either alone takes 0.11 - 0.13).  Three loads per stage behind the stage's
+    // weight issue instead: a weight wait then has at most the loads of three stages ago in front of it
     f32x4 aux[NB];
-    {
-      const float* ap = (first ? fp.aux0 : fp.aux + (size_t)(l - 1) * fp.aux_stride) + ro;
-#pragma unroll
-      for (int cb = 0; cb < NB; ++cb) aux[cb] = *reinterpret_cast<const f32x4*>(ap + 16 * cb);
-      ys0 += NB;
-    }
+    const float* ap = (first ? fp.aux0 : fp.aux + (size_t)(l - 1) * fp.aux_stride) + ro;
     float sB, invB;
     wire_x2_scales(wire_amax_read(fp.wamax + (size_t)(l - 1) * fp.wamax_stride, c.lane), sB, invB);
     (void)sB;
 #pragma unroll
     for (int j = 0; j < S; ++j) {
-      fx_stage_top<NB, RING, 0, FusedBwdParams, W>(fp, c, RING == 3 ? ys1 + ys0 : ys0);
+      fx_stage_top<NB, RING, (ABL & 16) ? 12 : 0, FusedBwdParams, W>(fp, c, RING == 3 ? ys1 + ys0 : ys0);
       ys1 = ys0; ys0 = 0;
+      {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int cb = 3 * j + q;
+          if (cb < NB) {
+            if constexpr (ABL & 1) { aux[cb] = f32x4{0.3f, 0.2f, 0.1f, 0.4f}; asm volatile("" : "+v"(aux[cb])); }
+            else { aux[cb] = *reinterpret_cast<const f32x4*>(ap + 16 * cb); ys0 += 1; }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       const unsigned char* Sb = c.ring + c.buf * STAGE + c.lane * 16;
       const fx_f16x8 ah = __builtin_bit_cast(fx_f16x8, Fh[j]), al = __builtin_bit_cast(fx_f16x8, Fl[j]);
       fx_f16x8 bh[FX_PFD + 1], bl[FX_PFD + 1];
@@ -1004,15 +1021,20 @@ __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwd
       }
 #pragma unroll
       for (int cb = 0; cb < NB; ++cb) {
-        if (cb + FX_PFD < NB) {
+        if (cb + FX_PFD < NB && !(ABL & 32)) {
           bh[(cb + FX_PFD) % (FX_PFD + 1)] = *reinterpret_cast<const fx_f16x8*>(Sb + (cb + FX_PFD) * 1024);
           bl[(cb + FX_PFD) % (FX_PFD + 1)] = *reinterpret_cast<const fx_f16x8*>(Sb + (NB + cb + FX_PFD) * 1024);
         }
-        const fx_f16x8 xh = bh[cb % (FX_PFD + 1)], xl = bl[cb % (FX_PFD + 1)];
-        if (j == 0) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, ah, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        else FX_MFMA(xl, ah, acc[cb]);
-        FX_MFMA(xh, al, acc[cb]);
-        FX_MFMA(xh, ah, acc[cb]);
+        fx_f16x8 xh = bh[(ABL & 32) ? 0 : cb % (FX_PFD + 1)], xl = bl[(ABL & 32) ? 0 : cb % (FX_PFD + 1)];
+        if constexpr (ABL & 32) { asm volatile("" : "+v"(xh)); asm volatile("" : "+v"(xl)); }
+        if constexpr (ABL & 8) {
+          asm volatile("" :: "v"(xh), "v"(xl), "v"(ah), "v"(al));
+        } else {
+          if (j == 0) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, ah, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          else FX_MFMA(xl, ah, acc[cb]);
+          FX_MFMA(xh, al, acc[cb]);
+          FX_MFMA(xh, ah, acc[cb]);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       c.t += 1;
@@ -1052,6 +1074,7 @@ __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwd
           if (ACT == ACT_RELU) out = aux[cb][e];
           v = real_act_bwd_lean<ACT>(go, aux[cb][e], out, om, fp.s);
         }
+        if constexpr (ABL & 4) v = go + aux[cb][e];
         gl[e] = valid ? v : 0.f;
         amx = __builtin_fmaxf(amx, __builtin_fabsf(gl[e]));
       }
@@ -1072,7 +1095,8 @@ __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwd
             *reinterpret_cast<f32x4*>(rp + 4 * q) = f32x4{sv[4 * q], sv[4 * q + 1], sv[4 * q + 2], sv[4 * q + 3]};
         }
       } else {
-        *reinterpret_cast<f32x4*>(gp + 16 * cb) = gl;
+        if constexpr (ABL & 2) asm volatile("" :: "v"(gl));
+        else *reinterpret_cast<f32x4*>(gp + 16 * cb) = gl;
       }
       acc[cb] = gl;
     }
@@ -1087,7 +1111,7 @@ __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwd
       }
       return;                                            // (first is the last link)
     }
-    ys0 += NB;
+    if constexpr (!(ABL & 2)) ys0 += NB;
     if (first) return;
     // the next link's operand scale from this wave's maximum; the tensor's maximum for the weight-gradient GEMM
 #pragma unroll
@@ -1125,12 +1149,15 @@ static std::atomic<int> g_fused_final{fx_env("WIRE_FUSED_FINAL", 0)};
 bool fused_final_enabled() { return g_fused_final != 0 && fused_train_enabled(); }
 int fused_bwd_knob();
 void fused_bwd_knob_set(int v);
+void fxb_ablate_set(int v);
 void fused_bwd_w_set(int v);
+int fused_bwd_w_get();
 int fused_tune_get(const char* key) {
   if (!strcmp(key, "fused_fwd")) return g_fused_fwd;
   if (!strcmp(key, "fused_train")) return g_fused_train;
   if (!strcmp(key, "fused_bwd")) return fused_bwd_knob();
   if (!strcmp(key, "fused_final")) return g_fused_final;
+  if (!strcmp(key, "fused_bwd_w")) return fused_bwd_w_get();
   return -1;
 }
 int fused_tune_set(const char* key, int value) {
@@ -1138,6 +1165,9 @@ int fused_tune_set(const char* key, int value) {
   if (!strcmp(key, "fused_train") && value >= 0 && value <= 1) { g_fused_train = value; return 0; }
   if (!strcmp(key, "fused_bwd") && value >= 0 && value <= 1) { fused_bwd_knob_set(value); return 0; }
   if (!strcmp(key, "fused_final") && value >= 0 && value <= 1) { g_fused_final = value; return 0; }
+#ifdef WIRE_FX_ABLATE
+  if (!strcmp(key, "fxb_ablate") && value >= 0 && value <= 127) { fxb_ablate_set(value); return 0; }
+#endif
   if (!strcmp(key, "fused_bwd_w") && (value == 4 || value == 8)) { fused_bwd_w_set(value); return 0; }
 #ifdef WIRE_FX_ABLATE
   if (!strcmp(key, "fx_ablate") && value >= 0 && value <= 15) { g_fx_ablate = value; return 0; }
@@ -1264,18 +1294,41 @@ bool fused_bwd_shape(int kind, int P) { return (kind == NK_SIREN || kind == NK_G
 // derivative, maxima, splits) runs beside the other's MFMAs, which the two waves of a SIMD inside ONE workgroup cannot do
 // (they meet at every stage barrier); price: the weight stream is fetched per 64 rows instead of per 128.
 static std::atomic<int> g_fused_bwd_w{fx_env("WIRE_FUSED_BWD_W", 8)};   // (A/B on three nets, two rounds each: no difference -- profiles/r04_fused_bwd_w_ab.txt)
-template <int KIND, int W>
+#ifdef WIRE_FX_ABLATE
+static std::atomic<int> g_fxb_ablate{0};
+#endif
+template <int KIND, int W, int ABL = 0>
 static hipError_t fxb_launch_w(hipStream_t s, const FusedBwdParams& fp) {
   constexpr int NB = 16, RING = W == 8 ? 3 : 2, LDS = RING * NB * 2048;
-  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_bwd_kernel<KIND, NB, RING, W>),
+  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_bwd_kernel<KIND, NB, RING, W, ABL>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (attr != hipSuccess) return attr;
   const unsigned grid = (unsigned)((fp.n + 16 * W - 1) / (16 * W));
-  hipLaunchKernelGGL((fused_bwd_kernel<KIND, NB, RING, W>), dim3(grid), dim3(64 * W), LDS, s, fp);
+  hipLaunchKernelGGL((fused_bwd_kernel<KIND, NB, RING, W, ABL>), dim3(grid), dim3(64 * W), LDS, s, fp);
   return hipGetLastError();
 }
 template <int KIND>
 static hipError_t fxb_launch_t(hipStream_t s, const FusedBwdParams& fp, int W) {
+#ifdef WIRE_FX_ABLATE
+  if constexpr (KIND == NK_SIREN) {
+    switch (g_fxb_ablate.load()) {
+      case 1: return fxb_launch_w<KIND, 8, 1>(s, fp);
+      case 2: return fxb_launch_w<KIND, 8, 2>(s, fp);
+      case 3: return fxb_launch_w<KIND, 8, 3>(s, fp);
+      case 4: return fxb_launch_w<KIND, 8, 4>(s, fp);
+      case 7: return fxb_launch_w<KIND, 8, 7>(s, fp);
+      case 8: return fxb_launch_w<KIND, 8, 8>(s, fp);
+      case 16: return fxb_launch_w<KIND, 8, 16>(s, fp);
+      case 23: return fxb_launch_w<KIND, 8, 23>(s, fp);
+      case 32: return fxb_launch_w<KIND, 8, 32>(s, fp);
+      case 64: return fxb_launch_w<KIND, 8, 64>(s, fp);
+      case 55: return fxb_launch_w<KIND, 8, 55>(s, fp);
+      case 119: return fxb_launch_w<KIND, 8, 119>(s, fp);
+      case 127: return fxb_launch_w<KIND, 8, 127>(s, fp);
+      default: break;
+    }
+  }
+#endif
   return W == 8 ? fxb_launch_w<KIND, 8>(s, fp) : fxb_launch_w<KIND, 4>(s, fp);
 }
 // *tile_rows: rows per workgroup of this launch = rows per block of fp.crp
@@ -1297,3 +1350,9 @@ hipError_t launch_fused_bwd(hipStream_t s, int kind, int P, const FusedBwdParams
 int fused_bwd_knob() { return g_fused_bwd; }
 void fused_bwd_knob_set(int v) { g_fused_bwd = v; }
 void fused_bwd_w_set(int v) { g_fused_bwd_w = v; }
+int fused_bwd_w_get() { return g_fused_bwd_w; }
+#ifdef WIRE_FX_ABLATE
+void fxb_ablate_set(int v) { g_fxb_ablate = v; }
+#else
+void fxb_ablate_set(int) {}
+#endif
