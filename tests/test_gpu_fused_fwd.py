@@ -109,10 +109,14 @@ TRAIN_CASES = {
     "wire_k128_2x": (dict(nonlin="wire", hidden_features=182, first_omega_0=7.0, hidden_omega_0=7.0, scale=6.0), 2),
     "siren_1x256": (dict(nonlin="siren", hidden_features=256, first_omega_0=30.0, hidden_omega_0=30.0), 1),
     "relu_posenc_3x256": (dict(nonlin="relu", hidden_features=256, pos_encode=True, sidelength=512), 3),
+    # 3-D coordinates and one output (the occupancy drivers' shape, wire_occupancy.py:43-44): D = 3 in the chain's first-layer
+    # sums, O = 1 in the final stage, two members in the weight-gradient batch
+    "gauss_2x256_3d": (dict(nonlin="gauss", hidden_features=256, scale=10.0, in_features=3, out_features=1), 2),
+    "relu_2x256_3d": (dict(nonlin="relu", hidden_features=256, in_features=3, out_features=1), 2),
 }
 
 
-FINAL_CASES = ["siren_4x256", "gauss_3x256", "relu_4x256", "siren_1x256", "relu_posenc_3x256"]
+FINAL_CASES = ["siren_4x256", "gauss_3x256", "relu_4x256", "siren_1x256", "relu_posenc_3x256", "gauss_2x256_3d"]
 
 
 @pytest.mark.parametrize("case,final", [(c, 0) for c in TRAIN_CASES] + [(c, 1) for c in FINAL_CASES])
@@ -136,18 +140,19 @@ def test_fused_training_forward_vs_layerwise_and_fp64_oracle(case, final):
     assert L.wire_tune_get(b"fused_train") == 1
     was_final = L.wire_tune_get(b"fused_final")
     _lib.check(L.wire_tune_set(b"fused_final", final))
-    grid = (131, 97)                                     # 12 707 rows: 99 workgroups and 35 rows
-    N = grid[0] * grid[1]
+    Dn, On = kw.pop("in_features", 2), kw.pop("out_features", 3)
+    grid = (131, 97) if Dn == 2 else (23, 29, 19)        # 12 707 rows: 99 workgroups and 35 rows; 12 673 = 99 and 1 row
+    N = int(np.prod(grid))
     g = torch.Generator().manual_seed(9)
-    target = torch.rand(N, 3, generator=g)
+    target = torch.rand(N, On, generator=g)
     perm = torch.randperm(N, generator=g)
     res = {}
     try:
         for knob in (1, 0):
             _lib.check(L.wire_tune_set(b"fused_train", knob))
             torch.manual_seed(6)
-            model = models.get_INR(in_features=2, out_features=3, hidden_layers=Ln, **kw).to(DEV)
-            tr = FusedTrainer(model, grid, target, lr=0.0, keep_rec=True)
+            model = models.get_INR(in_features=Dn, out_features=On, hidden_layers=Ln, **kw).to(DEV)
+            tr = FusedTrainer(model, grid, target, lr=0.0, keep_rec=True, coords_style="numpy" if Dn == 3 else "torch")
             loss = tr.step(perm.to(DEV))
             torch.cuda.synchronize()
             res[knob] = (float(loss.item()), tr.flat_grad.cpu().numpy().copy(), tr.rec.cpu().numpy()[perm.numpy()].copy())
@@ -157,7 +162,7 @@ def test_fused_training_forward_vs_layerwise_and_fp64_oracle(case, final):
         _lib.check(L.wire_tune_set(b"fused_final", was_final))
     assert not np.array_equal(res[0][1], res[1][1]), "the knob did not switch kernels"
     P = params_np(model)
-    coords = wo.image_coords(*grid)[perm.numpy()]
+    coords = (wo.image_coords(*grid) if Dn == 2 else wo.volume_coords(*grid))[perm.numpy()]
     tgt = target.numpy()[perm.numpy()]
     om1, om, sc = kw.get("first_omega_0", 30.0), kw.get("hidden_omega_0", 30.0), kw.get("scale", 10.0)
     nf = wo.posenc_num_frequencies(2, kw["sidelength"]) if kw.get("pos_encode") else None
