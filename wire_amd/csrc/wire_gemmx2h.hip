@@ -456,14 +456,19 @@ static std::atomic<int> g_x2_amode{x2_env("WIRE_X2_AMODE", 2)};
 // accumulators (0 = the fill-the-chip policy of gemmx2_tn_splits alone).  A shorter chain means more row splits, i.e.
 // more slabs for wgrad_reduce_kernel: the knob of the summation-order measurement (tools/wgrad_order_probe.py).
 static std::atomic<int> g_x2_tn_rows{x2_env("WIRE_X2_TN_ROWS", 0)};
+// "x2_tn_p384" / WIRE_X2_TN_P384: waves of the weight-gradient workgroup at P = 384 (K = 181) -- 8 (default, round 4): 48
+// features of G per wave, every SIMD carries two waves; 6: 64 features per wave (round 3)
+static std::atomic<int> g_x2_tn_p384{x2_env("WIRE_X2_TN_P384", 8)};
 int gemmx2h_tune_get(const char* key) {
   if (!strcmp(key, "x2_amode")) return g_x2_amode;
   if (!strcmp(key, "x2_tn_rows")) return g_x2_tn_rows;
+  if (!strcmp(key, "x2_tn_p384")) return g_x2_tn_p384;
   return -1;
 }
 int gemmx2h_tune_set(const char* key, int value) {
   if (!strcmp(key, "x2_amode") && value >= 0 && value <= 2) { g_x2_amode = value; return 0; }
   if (!strcmp(key, "x2_tn_rows") && value >= 0 && (value == 0 || value >= 256)) { g_x2_tn_rows = value; return 0; }
+  if (!strcmp(key, "x2_tn_p384") && (value == 6 || value == 8)) { g_x2_tn_p384 = value; return 0; }
   return -1;
 }
 
@@ -565,7 +570,14 @@ WIRE_DEVINL x2s16x4 x2_lds_tr16(const unsigned char* p) {
 // wire_store_out4; 1 / scale from the host); 2 / 3 (round 4, the fused training forward of siren / gauss nets stores no out_l at
 // all): the pre-activation r = c lin the forward's activation was evaluated on -- the loader evaluates sin(2 pi r) (2) or
 // exp2(-r^2) (3) again, the very instructions of wire_fused.hip's producer, and splits with the fixed scale 1 / z_pre_inv.
-template <int WM, int WN, int ZMODE>
+// RB = 16-feature blocks of G per wave (4: a wave owns 64 x 128 of the tile).  RB = 3 with (WM, WN) = (8, 1) is the P = 384
+// shape of round 4 (hidden_features = 256 through the reference's API, K = 181): 8 waves x 48 features = 384 x 128 -- the
+// (6, 1) shape's 6 waves leave two SIMDs of a CU with one wave and two with two, so the workgroup runs at the pace of 8 waves'
+// work on 6 waves' results; with 8 waves of 3 x 8 blocks every SIMD carries two waves of 72 MFMAs per stage (96 before).  Its 12
+// block pairs of G deal out to the 8 waves as 6 loader units each: pairs w (passes 0, 2), w + 4 (passes 1, 3) and, for waves
+// 0-3, w + 8 (passes 0, 2), for waves 4-7, w - 4 + 8 ... i.e. pair (w + 8) mod 12 with passes (1, 3) -- every pair gets its four
+// passes from two waves, whose bias sums meet in the LDS reduction.
+template <int WM, int WN, int ZMODE, int RB = 4>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
     const float* __restrict__ G, int ldg, const float* __restrict__ Z, int ldz, long long n, int Pm, int Pn,
     int tiles_n, int nsplit, long long chunk, float* __restrict__ slab, float* __restrict__ bslab, int tiles,
@@ -583,10 +595,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
     if (amax_z) amax_z += by * amax_step;
   }
   constexpr int NW = WM * WN;                       // waves
-  constexpr int TM = 64 * WM, TN = 128 * WN;        // tile: features of G x features of Z
+  constexpr int TM = 16 * RB * WM, TN = 128 * WN;   // tile: features of G x features of Z
+  constexpr bool G3 = RB == 3;                      // the (8, 1) x 48-feature shape: explicit loader dealing (above)
+  static_assert(RB == 4 || (RB == 3 && WM == 8 && WN == 1), "wave tiles: 64 x 128, or 48 x 128 in the 8-wave P = 384 shape");
   constexpr int GPLANE = X2T_TK * TM * 2, ZPLANE = X2T_TK * TN * 2;   // bytes of one fp16 plane of a stage
   constexpr int STAGE = 2 * GPLANE + 2 * ZPLANE;    // G h, G l, Z h, Z l
-  constexpr int UG = 8 * WM, UZ = 16 * WN;          // loader unit pairs (2 feature blocks x 8 row slots x 4 quads) per stage
+  constexpr int UG = TM / 8, UZ = 16 * WN;          // loader unit pairs (2 feature blocks x 8 row slots x 4 quads) per stage
   constexpr int IG = (UG + NW - 1) / NW, IZ = (UZ + NW - 1) / NW;     // ... per wave
   constexpr int PG = TM / 32, PZ = TN / 32;         // feature-block pairs per operand
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
@@ -625,18 +639,27 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
   // a Z tile that sticks out of the row (P = 448: the fourth 128-feature tile has 64): its loads stay inside the row
   const bool z_edge = WN == 1 && n_base + TN > Pn;      // ((4, 2) only runs on widths that are multiples of 256)
 
-  f32x4 acc[4][8];
+  f32x4 acc[RB][8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RB; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // G units of wave w: block pairs w + NW b, b < NB = PG / NW (1 at (4, 2), 2 at (WM, 1)), each in all 4 passes: unit i =
   // (block pair w + NW (i % NB), pass i / NB) -- the pass is a compile-time constant, the block pair one scalar.  Z units:
   // (4, 2): block pair w, pass i, likewise; (WM, 1): 16 units dealt round-robin, u = w + NW i < 16, pair u & 3, pass u >> 2.
   // Bias sums: one running sum per block pair of this wave, all passes added up.
-  static_assert(PG % NW == 0 && IG == 4 * (PG / NW), "the block pairs of G must deal out evenly to the waves");
+  static_assert(G3 || (PG % NW == 0 && IG == 4 * (PG / NW)), "the block pairs of G must deal out evenly to the waves");
+  static_assert(!G3 || (PG == 12 && IG == 6), "8 waves x 6 units = 12 block pairs x 4 passes");
   static_assert(PZ == NW || PZ == 4, "Z units: one block pair per wave, or 4 block pairs dealt round-robin");
-  constexpr int NB = PG / NW;
+  constexpr int NB = G3 ? 3 : PG / NW;              // block pairs (= bias sums) of a wave
+  // G3: unit i of wave w = (pair, pass): 0 (w, 0), 1 (pB, hiw), 2 (w + 4, 1), 3 (w, 2), 4 (pB, 2 + hiw), 5 (w + 4, 3) with
+  // hiw = w >= 4, pB = (w + 8) mod 12
+  const int hiw = wave >= 4 ? 1 : 0;
+  const int g3_pb = hiw ? wave - 4 : wave + 8;
+  auto g3_pair = [&](const int i) { return (i % 3) == 0 ? wave : ((i % 3) == 1 ? g3_pb : wave + 4); };
+  // row of the pass inside the 32-row stage (pass_row below) and its LDS offset (pass x 256)
+  auto g3_row = [&](const int i) { return (i % 3) == 1 ? 16 * hiw + (i >= 3 ? 4 : 0) : (i == 0 ? 0 : i == 2 ? 16 : i == 3 ? 4 : 20); };
+  auto g3_pass = [&](const int i) { return (i % 3) == 1 ? hiw + (i >= 3 ? 2 : 0) : (i == 0 ? 0 : i == 2 ? 1 : i == 3 ? 2 : 3); };
   constexpr bool ZFIX = (PZ == NW);
   f32x4 bsum[NB];
 #pragma unroll
@@ -662,9 +685,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
     const int rbase = ks * X2T_TK + l_row0;
 #pragma unroll
     for (int i = 0; i < IG; ++i) {
-      const int fp = wave + NW * (i % NB), t = i / NB;
-      const bool ok = !tail || rbase + pass_row(t) < nrows;
-      R.g[i] = ok ? *reinterpret_cast<const f32x4*>(gb + (size_t)pass_row(t) * ldg + 32 * fp + g_off) : zero4;
+      if constexpr (G3) {
+        const int fp = g3_pair(i), pr = g3_row(i);
+        const bool ok = !tail || rbase + pr < nrows;
+        R.g[i] = ok ? *reinterpret_cast<const f32x4*>(gb + (size_t)pr * ldg + 32 * fp + g_off) : zero4;
+      } else {
+        const int fp = wave + NW * (i % NB), t = i / NB;
+        const bool ok = !tail || rbase + pass_row(t) < nrows;
+        R.g[i] = ok ? *reinterpret_cast<const f32x4*>(gb + (size_t)pass_row(t) * ldg + 32 * fp + g_off) : zero4;
+      }
     }
 #pragma unroll
     for (int i = 0; i < IZ; ++i) {
@@ -681,7 +710,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
     unsigned char* S = smem_t + buf * STAGE + l_st;
 #pragma unroll
     for (int i = 0; i < IG; ++i) {
-      const int fp = wave + NW * (i % NB), t = i / NB;
+      const int fp = G3 ? g3_pair(i) : wave + NW * (i % NB), t = G3 ? g3_pass(i) : i / NB;
       const f32x4 gv = R.g[i];
       unsigned h0, l0, h1, l1;
       x2_split2(gv[0], gv[1], s_g, h0, l0);
@@ -723,8 +752,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
 
   // fragment reads (plane order in LDS: G h, G l, Z h, Z l)
   const int hi = lane >> 5;
-  const int g_hh = lane * 8 + wave_m * (4 * 1024);
-  const int g_pr = (lane & 31) * 8 + (hi ? 0 : 1) * GPLANE + wave_m * (4 * 1024);                    // G (l | h)
+  const int g_hh = lane * 8 + wave_m * (RB * 1024);
+  const int g_pr = (lane & 31) * 8 + (hi ? 0 : 1) * GPLANE + wave_m * (RB * 1024);                   // G (l | h)
   const int z_hh = 2 * GPLANE + lane * 8 + wave_n * (8 * 1024);
   const int z_pr = 2 * GPLANE + (lane & 31) * 8 + (hi ? 1 : 0) * ZPLANE + wave_n * (8 * 1024);      // Z (h | l)
 
@@ -745,14 +774,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
     for (int ps = 0; ps < 3; ++ps) {
       const int go = ps == 2 ? g_hh : g_pr + 256 * ps;
       const int zo = ps == 2 ? z_hh : z_pr + 256 * ps;
-      f16x8 gf[4];
+      f16x8 gf[RB];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) gf[i] = frag(S + go + i * 1024);
+      for (int i = 0; i < RB; ++i) gf[i] = frag(S + go + i * 1024);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const f16x8 zf = frag(S + zo + j * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) X2_MFMA(zf, gf[i], acc[i][j]);
+        for (int i = 0; i < RB; ++i) X2_MFMA(zf, gf[i], acc[i][j]);
       }
       __builtin_amdgcn_sched_barrier(0);               // (or the next pass's fragment reads are hoisted up here)
     }
@@ -795,17 +824,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
 
   if (do_bias) {
     // the 8 row-slot lanes of a feature quad and the 4 passes of a block pair: sum through LDS (all fragment reads are done)
-    float* red = reinterpret_cast<float*>(smem_t);       // [8 row slots][TM features]
+    // (G3: a block pair's passes come from two waves -- the even passes from one, the odd ones from another: 16 partial rows)
+    constexpr int RR = G3 ? 16 : 8;
+    float* red = reinterpret_cast<float*>(smem_t);       // [8 row slots (x 2 pass parities)][TM features]
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int fp = wave + NW * i;
-      *reinterpret_cast<f32x4*>(&red[l_rs * TM + 32 * fp + l_feat]) = bsum[i];
+      const int fp = G3 ? g3_pair(i) : wave + NW * i;
+      const int hf = G3 ? (g3_pass(i) & 1) : 0;
+      *reinterpret_cast<f32x4*>(&red[(l_rs + 8 * hf) * TM + 32 * fp + l_feat]) = bsum[i];
     }
     __syncthreads();
     for (int f = tid; f < TM; f += 64 * NW) {
       float v = 0.f;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v += red[r * TM + f];
+      for (int r = 0; r < RR; ++r) v += red[r * TM + f];
       bslab[(size_t)split * Pm + m_base + f] = v;
     }
   }
@@ -815,8 +847,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
   const float inv = inv_g * inv_z;
   const int rr = lane & 7, cq = 16 * ((lane >> 3) & 1) + 4 * (lane >> 4);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m_base + wave_m * 64 + 16 * i + rr;
+  for (int i = 0; i < RB; ++i) {
+    const int m = m_base + wave_m * (16 * RB) + 16 * i + rr;
 #pragma unroll
     for (int jp = 0; jp < 4; ++jp) {
       f32x4 xp, yp;
@@ -836,10 +868,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
 static int x2_tn_shape(int Pm, int Pn) {
   if ((Pm & 63) || (Pn & 63) || Pm < 64 || Pn < 64) return 0;
   if (Pm % 256 == 0 && Pn % 256 == 0) return 42;
-  if (Pm == 384) return 61;
+  if (Pm == 384) return g_x2_tn_p384 == 8 ? 381 : 61;   // 381: 8 waves x 48 features (round 4); 61: 6 waves x 64
   if (Pm == 448) return 71;
   return 0;
 }
+// tile of a shape code: G features x Z features
+static int x2_tn_tm(int shp) { return shp == 381 ? 384 : 64 * (shp / 10); }
+static int x2_tn_tn(int shp) { return shp == 381 ? 128 : 128 * (shp % 10); }
 bool gemmx2_tn_applies(int Pm, int Pn) { return x2_tn_shape(Pm, Pn) != 0; }
 // Row splits that fill the chip with ONE workgroup per CU.  Blocks are dealt round-robin over the 8 XCDs and split s runs
 // its tiles on XCD s % 8, so an XCD receives tiles * ceil(splits / 8) workgroups and has 32 CUs: one more than 32 and a CU
@@ -848,7 +883,7 @@ bool gemmx2_tn_applies(int Pm, int Pn) { return x2_tn_shape(Pm, Pn) != 0; }
 int gemmx2_tn_splits(int64_t n, int Pm, int Pn, int max_splits) {
   const int shp = x2_tn_shape(Pm, Pn);
   if (!shp) return 0;
-  const int TMf = 64 * (shp / 10), TNf = 128 * (shp % 10);
+  const int TMf = x2_tn_tm(shp), TNf = x2_tn_tn(shp);
   const int tiles = (Pm / TMf) * ((Pn + TNf - 1) / TNf);
   int s = tiles >= 32 ? 8 : 8 * (32 / tiles);
   int64_t by_rows = (n + 255) / 256;                     // at least 256 rows per split
@@ -878,7 +913,7 @@ int gemmx2_tn_batch_splits(int64_t n, int Pm, int Pn, int max_splits, int batch)
   // an XCD (32 CUs, one workgroup each) receives tiles x ceil(splits / 8) workgroups of EVERY member: 3 members x 11 = 33 ran
   // one workgroup behind the others on four XCDs and the launch took twice as long (the first edition: + 0.1 ms per step)
   const int shp = x2_tn_shape(Pm, Pn);
-  const int tiles = (Pm / (64 * (shp / 10))) * ((Pn + 128 * (shp % 10) - 1) / (128 * (shp % 10)));
+  const int tiles = (Pm / x2_tn_tm(shp)) * ((Pn + x2_tn_tn(shp) - 1) / x2_tn_tn(shp));
   const int groups = 32 / (tiles * batch);
   if (groups < 1) return 0;
   if (s > 8 * groups) s = 8 * groups;
@@ -887,28 +922,28 @@ int gemmx2_tn_batch_splits(int64_t n, int Pm, int Pn, int max_splits, int batch)
   return (int)((n + chunk - 1) / chunk);
 }
 
-template <int WM, int WN, int ZMODE>
+template <int WM, int WN, int ZMODE, int RB = 4>
 static hipError_t launch_x2_tn_z(hipStream_t s, dim3 grid, const float* G, int ldg, const float* Z, int ldz, int64_t n,
                                  int Pm, int Pn, int tiles_n, int used, long long chunk, float* slab, float* bslab,
                                  int tiles, const unsigned* amax_g, const unsigned* amax_z, float z_pre_inv,
                                  long long g_step, long long z_step, int amax_step) {
-  constexpr int STAGE = X2T_TK * (64 * WM + 128 * WN) * 4;
+  constexpr int STAGE = X2T_TK * (16 * RB * WM + 128 * WN) * 4;
   // > 64 KB of dynamic LDS needs the opt-in; per launch (a host-side call of about a microsecond), because the attribute
   // belongs to the current device's copy of the function and a process may drive more than one
-  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemmx2_tn16_kernel<WM, WN, ZMODE>),
+  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemmx2_tn16_kernel<WM, WN, ZMODE, RB>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
   if (attr != hipSuccess) return attr;
-  hipLaunchKernelGGL((gemmx2_tn16_kernel<WM, WN, ZMODE>), grid, dim3(64 * WM * WN), 2 * STAGE, s, G, ldg, Z, ldz,
+  hipLaunchKernelGGL((gemmx2_tn16_kernel<WM, WN, ZMODE, RB>), grid, dim3(64 * WM * WN), 2 * STAGE, s, G, ldg, Z, ldz,
                      (long long)n, Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles, amax_g, amax_z, z_pre_inv, g_step, z_step,
                      amax_step);
   return hipGetLastError();
 }
-template <int WM, int WN>
+template <int WM, int WN, int RB = 4>
 static hipError_t launch_x2_tn_t(hipStream_t s, dim3 grid, const float* G, int ldg, const float* Z, int ldz, int64_t n,
                                  int Pm, int Pn, int tiles_n, int used, long long chunk, float* slab, float* bslab,
                                  int tiles, const unsigned* amax_g, const unsigned* amax_z, float z_pre_inv, int z_act,
                                  long long g_step, long long z_step, int amax_step) {
-#define X2_TN_Z(M) launch_x2_tn_z<WM, WN, M>(s, grid, G, ldg, Z, ldz, n, Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles, amax_g, \
+#define X2_TN_Z(M) launch_x2_tn_z<WM, WN, M, RB>(s, grid, G, ldg, Z, ldz, n, Pm, Pn, tiles_n, used, chunk, slab, bslab, tiles, amax_g, \
                                             amax_z, z_pre_inv, g_step, z_step, amax_step)
   if constexpr (WM == 4 && WN == 2) {                      // the re-evaluating loaders: the 256-feature real nets only
     if (z_act == 2) return X2_TN_Z(2);
@@ -933,7 +968,7 @@ hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float*
   if (!shp || (ldg & 3) || (ldz & 3) || splits < 1 || n < 1 || !amax_g || (!amax_z && z_pre_inv == 0.f) ||
       (z_act != 0 && (z_act < 2 || z_act > 3 || z_pre_inv == 0.f)) || batch < 1 || batch > 8)
     return hipErrorInvalidValue;
-  const int TMf = 64 * (shp / 10), TNf = 128 * (shp % 10);
+  const int TMf = x2_tn_tm(shp), TNf = x2_tn_tn(shp);
   const int tiles_m = Pm / TMf, tiles_n = (Pn + TNf - 1) / TNf;
   long long chunk = (n + splits - 1) / splits;
   chunk = (chunk + 2 * X2T_TK - 1) / (2 * X2T_TK) * (2 * X2T_TK);
@@ -954,6 +989,7 @@ hipError_t launch_gemmx2_tn(hipStream_t s, const float* G, int ldg, const float*
   switch (shp) {
     case 42: return launch_x2_tn_t<4, 2>(X2_TN_ARGS);
     case 61: return launch_x2_tn_t<6, 1>(X2_TN_ARGS);
+    case 381: return launch_x2_tn_t<8, 1, 3>(X2_TN_ARGS);
     case 71: return launch_x2_tn_t<7, 1>(X2_TN_ARGS);
     default: return hipErrorInvalidValue;
   }
