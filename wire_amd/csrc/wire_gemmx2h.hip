@@ -797,7 +797,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemmx2_tn16_kernel(
   // (the (WM, 1) shapes stage 11 instead of 8 loads per lane: with both wave kinds in the code the allocator spills ~25
   // registers, and a spill reload waits, in vmcnt order, for the prefetched global loads -- measured 2 x the stage time at
   // P = 384; all their waves run the late schedule)
-  const bool early = WN == 2 && wave >= 4;
+  // (the 48-feature shape has the registers for both wave kinds: 216 without the stagger)
+  const bool early = (WN == 2 || G3) && wave >= 4;
   load_any(0);
   lstore(st, 0);
   if (early) load_any(1);
