@@ -183,6 +183,7 @@ struct Plan {
   std::vector<int64_t> off_fwd, off_dg, off_bias, off_fwd_x3, off_dg_x3, off_fwd_3m, off_dg_3m, off_fwd_x2, off_dg_x2;
   int64_t off_wf, off_bf, off_first, off_wamax, total_packed;   // off_wamax: max-|weight| slots, WIRE_AMAX_SLOTS per layer
   int64_t off_fx;    // k-permuted 2 x fp16 images of the hidden layers for the fused forward (wire_fused.hip), -1 = no such shape
+  bool k_split_out, k_recompute_out, k_first_sums, k_rstore, k_wgrad_batch, k_fused_fwd, k_fused_train, k_fused_bwd, k_fused_final;
   int64_t off_fxd;   // the same of the TRANSPOSED weights of layers L .. 1 (in that order) for the data-gradient chain, -1 = none
   std::vector<int64_t> tfloats;
 };
@@ -206,6 +207,13 @@ int make_plan(const wire_net_desc* d, Plan& p) {
   p.x3 = g_split_bf16 != 0;
   p.x2 = p.x3 && g_split_f16 != 0;
   p.m3 = (p.kind == WIRE_KIND_WIRE) && g_complex_3m && !p.x3;
+  // one snapshot of the knobs that decide FORMATS (what the forward stores and the backward of the same call reads): a
+  // wire_tune_set from another thread in the middle of wire_train_fwd_bwd must not split a call between two formats
+  // (the forward and the backward of the autograd path are separate calls: knobs must not change between them)
+  p.k_split_out = g_split_out != 0; p.k_recompute_out = g_recompute_out != 0; p.k_first_sums = g_first_sums != 0;
+  p.k_rstore = g_fused_rstore != 0; p.k_wgrad_batch = g_wgrad_batch != 0;
+  p.k_fused_fwd = fused_fwd_enabled(); p.k_fused_train = fused_train_enabled(); p.k_fused_bwd = fused_bwd_enabled();
+  p.k_fused_final = fused_final_enabled();
   p.first_gemm = p.F > 0;
   p.Din = p.first_gemm ? p.D + 2 * p.D * p.F : p.D;
   p.Pin0 = p.first_gemm ? rup(p.Din, 64) : 0;
@@ -369,8 +377,8 @@ float fused_act_scale(const Plan& p);
 // family with its pre-split activations and recompute_out (the formats that kernel writes), a bound on the activations (all
 // kinds but relu).  Decides the FORMAT of the stored out_l (pre-split at scale 1), so the backward asks the same question.
 bool fused_train_applies(const Plan& p, int64_t n) {
-  if (!fused_train_enabled() || p.off_fx < 0 || p.L < 1 || p.L > 8) return false;
-  if (!use_x2(p, n) || !gemmx2_tn_applies(p.Pl, p.P) || !g_split_out || !g_recompute_out) return false;
+  if (!p.k_fused_train || p.off_fx < 0 || p.L < 1 || p.L > 8) return false;
+  if (!use_x2(p, n) || !gemmx2_tn_applies(p.Pl, p.P) || !p.k_split_out || !p.k_recompute_out) return false;
   if (p.kind == WIRE_KIND_WIRE && p.P > 256 && env_int_("WIRE_FUSED_TRAIN_P384", 0) == 0) return false;
   if (p.kind != WIRE_KIND_RELU && fused_act_scale(p) == 0.f) return false;
   return fused_pre_scale(p.kind, p.w1, p.s) > 0.f && fused_pre_scale(p.kind, p.w, p.s) > 0.f;
@@ -378,17 +386,17 @@ bool fused_train_applies(const Plan& p, int64_t n) {
 // ... and its data gradients g_lin_L -> .. -> g_lin_1 as ONE kernel (the last link, layer 1 with the first layer's sums,
 // stays with the layer-by-layer kernel)
 bool fused_bwd_applies(const Plan& p, int64_t n) {
-  return fused_bwd_enabled() && p.off_fxd >= 0 && p.L >= 1 && fused_train_applies(p, n);
+  return p.k_fused_bwd && p.off_fxd >= 0 && p.L >= 1 && fused_train_applies(p, n);
 }
 // ... and then the sine / Gaussian nets store NO inner out_l and their inner lin_l as r = c lin (the argument the activation
 // was evaluated on): the chain differentiates on r, the weight-gradient loader evaluates act(r) again -- 0.8 GB per step less
 bool fused_rstore(const Plan& p, int64_t n) {
-  return (p.kind == WIRE_KIND_SIREN || p.kind == WIRE_KIND_GAUSS) && g_fused_rstore && fused_bwd_applies(p, n);
+  return (p.kind == WIRE_KIND_SIREN || p.kind == WIRE_KIND_GAUSS) && p.k_rstore && fused_bwd_applies(p, n);
 }
 float out_split_scale(const Plan& p, int64_t n, int l) {
-  if (!g_split_out || l < 1 || l >= p.L || p.kind == WIRE_KIND_RELU) return 0.f;
+  if (!p.k_split_out || l < 1 || l >= p.L || p.kind == WIRE_KIND_RELU) return 0.f;
   if (!use_x2(p, n) || !gemmx2_tn_applies(p.Pl, p.P)) return 0.f;
-  if (!g_recompute_out && p.kind != WIRE_KIND_SIREN) return 0.f;
+  if (!p.k_recompute_out && p.kind != WIRE_KIND_SIREN) return 0.f;
   if (fused_train_applies(p, n)) return 1.f;               // the fused forward splits its bounded activations unscaled
   double bound = 1.0;
   if (p.cplx) {
@@ -593,7 +601,7 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
   if (!save_for_bwd && do_final && x2) {
     // forward-only: the whole net in one kernel, activations in registers (wire_fused.hip)
     const float a_scale = fused_act_scale(p);
-    if (p.off_fx >= 0 && fused_fwd_enabled() && p.O <= 4 && p.L <= 8 && (a_scale != 0.f || p.kind == WIRE_KIND_RELU) &&
+    if (p.off_fx >= 0 && p.k_fused_fwd && p.O <= 4 && p.L <= 8 && (a_scale != 0.f || p.kind == WIRE_KIND_RELU) &&
         fused_pre_scale(p.kind, p.w1, p.s) > 0.f && fused_pre_scale(p.kind, p.w, p.s) > 0.f) {
       FusedFwdParams fp;
       fp.coords = coords; fp.n = n;
@@ -646,7 +654,7 @@ static int mlp_fwd_core(void* stream, const Plan& p, const float* packed, const 
     fp.out = A + a.out0; fp.out_stride = a.np * p.P;
     fp.amax_out = amax;
     fp.rstore = fused_rstore(p, n) ? 1 : 0;
-    if (loss && loss_done && !p.cplx && fused_final_enabled()) {
+    if (loss && loss_done && !p.cplx && p.k_fused_final) {
       // the final stage inside this kernel (wire_fused.hip: fx_tail_loss): lin_L / out_L are not stored at all
       fp.wf = packed + p.off_wf; fp.bfr = packed + p.off_bf;
       fp.target = loss->target; fp.idx = loss->idx; fp.first = loss->first; fp.gscale = loss->gscale;
@@ -755,11 +763,11 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
   auto wamax = [&](int l) { return reinterpret_cast<const unsigned*>(packed + p.off_wamax + (int64_t)l * WIRE_AMAX_SLOTS); };
   // (the fused path zeroed the slots before its final stage published max |g_lin_L|)
   if (x2 && do_final) HIPCHK(hipMemsetAsync(gamax, 0, (size_t)(p.L + 2) * WIRE_AMAX_SLOTS * sizeof(unsigned), s));
-  const bool first_sums = g_first_sums && p.cplx && p.x3 && p.L >= 1 &&
+  const bool first_sums = p.k_first_sums && p.cplx && p.x3 && p.L >= 1 &&
                           gemmx3_nt_is_h16(p.kind == WIRE_KIND_WIRE ? EPI_GABOR_BWD_FIRST : EPI_GABOR2D_BWD_FIRST, n);
   const int64_t crp_set = (int64_t)(colreduce_blocks(n) + 32) * p.ldu * 5;   // wire2d: second set of partial sums
   // the same for siren / gauss / relu with a native first layer: the epilogue of the layer-1 data gradient sums g_lin_0 [x | 1]
-  const bool first_sums_real = g_first_sums && !p.cplx && !p.first_gemm && p.x3 && p.L >= 1 &&
+  const bool first_sums_real = p.k_first_sums && !p.cplx && !p.first_gemm && p.x3 && p.L >= 1 &&
                                gemmx3_nt_is_h16(epi_bwd(p.kind), n);
 
   // ---- final linear + activation gradient of layer L
@@ -827,7 +835,7 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
   // operands a fixed step apart) run as ONE launch, each member accumulating L - 1 times the rows into a third of the slabs
   // (layer 1 joins when its activation operand has the form of the others': r_0 of the sine / Gaussian nets, relu's fp32 out_0)
   int wbatch = 0, wbatch_S = 0, wbatch_l0 = 2;
-  if (chain && g_wgrad_batch && x2 && gemmx2_tn_applies(p.Pl, p.P)) {
+  if (chain && p.k_wgrad_batch && x2 && gemmx2_tn_applies(p.Pl, p.P)) {
     const bool rs = fused_rstore(p, n);
     const int l0 = (rs || p.kind == WIRE_KIND_RELU) ? 1 : 2;
     const int nb = p.L - l0 + 1;
@@ -901,7 +909,7 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
       ep.i0 = lin_l(l - 1); ep.o0 = gnext; ep.ld0 = p.Pl;
       // hidden Gabor layer whose forward ran the lean 16 x 16 x 32 epilogue: out = act(lin) again, 8 B / element less
       // (real nets: only below a hidden layer -- the first layer's out comes from first_fwd_kernel's precise form)
-      ep.recompute_out = g_recompute_out && p.x3 && (p.cplx || l - 1 >= 1) && gemmx3_nt_is_h16(epi_fwd(p.kind), n);
+      ep.recompute_out = p.k_recompute_out && p.x3 && (p.cplx || l - 1 >= 1) && gemmx3_nt_is_h16(epi_fwd(p.kind), n);
       if (l == 1 && first_sums_real) { ep.coords = coords; ep.D = p.D; ep.cr_partial = Sx + sc.crp; ep.cr_C = p.K; }
     } else {
       epi = (p.kind == WIRE_KIND_WIRE) ? EPI_GABOR_BWD_FIRST : EPI_GABOR2D_BWD_FIRST;
@@ -911,7 +919,7 @@ static int mlp_bwd_core(void* stream, const Plan& p, const float* packed, const 
       // and bias gradient partials) instead of storing g_u for a separate pass
       if (first_sums) { ep.cr_partial = Sx + sc.crp; ep.cr_C = p.K; ep.cr_set = crp_set; }
       // (and re-evaluates out_0 from the u it recomputes anyway: first_fwd_kernel's own form, the same bits)
-      ep.recompute_out = g_recompute_out && p.x3 && p.kind == WIRE_KIND_WIRE && gemmx3_nt_is_h16(EPI_GABOR_BWD_FIRST, n);
+      ep.recompute_out = p.k_recompute_out && p.x3 && p.kind == WIRE_KIND_WIRE && gemmx3_nt_is_h16(EPI_GABOR_BWD_FIRST, n);
       ep.W0 = packed + first_native_off(p, 0); ep.b0 = packed + first_native_off(p, 1);
       if (p.per_layer == 4) { ep.W0b = packed + first_native_off(p, 2); ep.b0b = packed + first_native_off(p, 3); }
     }
@@ -1008,7 +1016,7 @@ extern "C" int wire_train_fwd_bwd_hooked(void* stream, const wire_net_desc* d, c
   }
   // with layer L on the 16 x 16 x 32 forward kernel (lean epilogue) the final stage evaluates out_L from lin_L itself,
   // bit for bit what that epilogue would have stored: out_L is neither written nor read (1 GB less HBM traffic)
-  const bool recomp = g_recompute_out && p.x3 && p.kind != WIRE_KIND_RELU && gemmx3_nt_is_h16(epi_fwd(p.kind), n);
+  const bool recomp = p.k_recompute_out && p.x3 && p.kind != WIRE_KIND_RELU && gemmx3_nt_is_h16(epi_fwd(p.kind), n);
   const ActLayout a = act_layout(p, n, 1);
   const ScratchLayout sc = scratch_layout(p, n);
   if (!scratch || scratch_bytes < sc.total * 4) return fail(WIRE_ERR_SIZE, "scratch too small");
