@@ -383,13 +383,13 @@ bool fused_train_applies(const Plan& p, int64_t n) {
   if (p.kind != WIRE_KIND_RELU && fused_act_scale(p) == 0.f) return false;
   return fused_pre_scale(p.kind, p.w1, p.s) > 0.f && fused_pre_scale(p.kind, p.w, p.s) > 0.f;
 }
-// ... and its data gradients g_lin_L -> .. -> g_lin_1 as ONE kernel (the last link, layer 1 with the first layer's sums,
-// stays with the layer-by-layer kernel)
+// ... and its data gradients g_lin_L -> .. -> g_lin_1 -> the first layer's gradient sums as ONE kernel
 bool fused_bwd_applies(const Plan& p, int64_t n) {
   return p.k_fused_bwd && p.off_fxd >= 0 && p.L >= 1 && fused_train_applies(p, n);
 }
-// ... and then the sine / Gaussian nets store NO inner out_l and their inner lin_l as r = c lin (the argument the activation
-// was evaluated on): the chain differentiates on r, the weight-gradient loader evaluates act(r) again -- 0.8 GB per step less
+// ... and then the sine / Gaussian nets store NO out_l below L and their lin_l (l < L, layer 0 included) as r = c lin (the
+// argument the activation was evaluated on): the chain differentiates on r, the weight-gradient loader evaluates act(r) again
+// -- 1.3 GB per step less
 bool fused_rstore(const Plan& p, int64_t n) {
   return (p.kind == WIRE_KIND_SIREN || p.kind == WIRE_KIND_GAUSS) && p.k_rstore && fused_bwd_applies(p, n);
 }

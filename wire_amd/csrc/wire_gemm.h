@@ -197,7 +197,7 @@ struct FusedBwdParams {
   float* g = nullptr; long long g_stride = 0;             // g_lin_l at g + l * g_stride, rows of P floats, l = 1 .. L: g_lin_L is
                                                           // read, g_lin_{L-1} .. g_lin_1 are written (buffers padded to 128 rows)
   unsigned* gamax = nullptr;                              // max |g_lin_l| slots at gamax + l * WIRE_AMAX_SLOTS (L: read; below: written)
-  const float* aux = nullptr; long long aux_stride = 0;   // lin_l (relu: out_l) at aux + l * aux_stride, l = 1 .. L - 1
+  const float* aux = nullptr; long long aux_stride = 0;   // lin_l (rstore: r_l; relu: out_l) at aux + l * aux_stride, l = 1 .. L - 1
   const float* aux0 = nullptr;                            // lin_0 (rstore: r_0 = c_first lin_0; relu: out_0), rows of P floats
   const unsigned char* wimg = nullptr;                    // k-permuted images of the TRANSPOSED weights, layers L, L - 1, .. 1 back to back
   const unsigned* wamax = nullptr; int wamax_stride = 0;  // max |W_l| slots of layer l at wamax + (l - 1) * wamax_stride
