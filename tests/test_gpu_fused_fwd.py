@@ -111,12 +111,18 @@ TRAIN_CASES = {
     "relu_posenc_3x256": (dict(nonlin="relu", hidden_features=256, pos_encode=True, sidelength=512), 3),
     # 3-D coordinates and one output (the occupancy drivers' shape, wire_occupancy.py:43-44): D = 3 in the chain's first-layer
     # sums, O = 1 in the final stage, two members in the weight-gradient batch
+    # widths below 256 (padded to P = 256: the pad features' activations are act(0) -- 1 for the Gaussian -- behind zero weights)
+    # and more layers than the bench nets
+    "gauss_3x200": (dict(nonlin="gauss", hidden_features=200, scale=10.0), 3),
+    "siren_6x250": (dict(nonlin="siren", hidden_features=250, first_omega_0=30.0, hidden_omega_0=30.0), 6),
+    "relu_5x193_4out": (dict(nonlin="relu", hidden_features=193, out_features=4), 5),
     "gauss_2x256_3d": (dict(nonlin="gauss", hidden_features=256, scale=10.0, in_features=3, out_features=1), 2),
     "relu_2x256_3d": (dict(nonlin="relu", hidden_features=256, in_features=3, out_features=1), 2),
 }
 
 
-FINAL_CASES = ["siren_4x256", "gauss_3x256", "relu_4x256", "siren_1x256", "relu_posenc_3x256", "gauss_2x256_3d"]
+FINAL_CASES = ["siren_4x256", "gauss_3x256", "relu_4x256", "siren_1x256", "relu_posenc_3x256", "gauss_2x256_3d", "gauss_3x200",
+               "relu_5x193_4out"]
 
 
 @pytest.mark.parametrize("case,final", [(c, 0) for c in TRAIN_CASES] + [(c, 1) for c in FINAL_CASES])
