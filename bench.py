@@ -181,6 +181,11 @@ def alg_hbm_bytes(kind, K, Ln):
         return None
     P = (K + 63) // 64 * 64
     relu = kind == "relu"
+    if P == 256 and os.environ.get("WIRE_FUSED_TRAIN", "1") != "0":
+        # round 4, the whole-net kernels: the storing forward writes L + 1 rows (r_0 .. r_{L-1}, lin_L;
+        # relu: out_0 .. out_L), the chain reads L + 1 (r_l / out_l, g_lin_L) and writes L - 1 (L with positional encoding:
+        # not counted), the one weight-gradient launch reads 2 L, the final stage reads 1 and writes 1
+        return 4 * (5 * Ln + 3) * P
     floats = (1 if relu else 2) * P                                   # first layer
     floats += Ln * P + (0 if relu else Ln * P) + (Ln if relu else Ln - 1) * P   # forward: reads, lin, out
     floats += 2 * P                                                   # final stage
