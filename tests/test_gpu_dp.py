@@ -29,6 +29,28 @@ def _make(dev, micro, seed=0):
     return model, FusedTrainer(model, (H, W), target, lr=5e-3, niters=100, micro_shards=micro)
 
 
+HB, WB = 96, 100         # 9 600 points per step: the whole-net kernels (>= 4096 rows), 75 workgroups
+
+
+def _make_big(dev, seed=0):
+    """A 256-feature sine net on enough rows for the round-4 path: storing forward, data-gradient chain (its gradients become
+    ready in the order L + 1, L .. 1, 0 of the announcements), all hidden weight gradients as one launch."""
+    from wire_amd.modules import models
+    from wire_amd.trainer import FusedTrainer
+    torch.manual_seed(seed)
+    model = models.get_INR(nonlin="siren", in_features=2, out_features=3, hidden_features=256, hidden_layers=3,
+                           first_omega_0=30.0, hidden_omega_0=30.0).to(dev)
+    g = torch.Generator().manual_seed(3)
+    target = torch.rand(HB * WB, 3, generator=g)
+    return model, FusedTrainer(model, (HB, WB), target, lr=1e-4, niters=100)
+
+
+def _run_big(tr, dev):
+    losses = [tr.step_hashed(e) for e in range(4)]
+    torch.cuda.synchronize()
+    return [float(l.item()) for l in losses]
+
+
 def _run(tr, dev, hashed=False):
     g = torch.Generator().manual_seed(11)
     losses = []
@@ -98,7 +120,7 @@ def test_two_ranks_hashed_shuffle_and_broadcast(tmp_path):
     assert np.abs(f0 - tr.flat.detach().cpu().numpy()).max() < 0.05 * 5e-3
 
 
-def _worker_rccl_direct(rank, world, port, out_dir, overlap="layer"):
+def _worker_rccl_direct(rank, world, port, out_dir, overlap="layer", big=False):
     """One rank, backend nccl (= RCCL), WIRE_DP_FORCE=1: the collective path stays live, FlatGradAllReducer opens its own
     communicator (parallel.RcclDirect: ncclGetUniqueId -> broadcast of the 128 bytes -> ncclCommInitRank) and issues
     ncclAllReduce on the compute stream."""
@@ -113,12 +135,12 @@ def _worker_rccl_direct(rank, world, port, out_dir, overlap="layer"):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    model, tr = _make(dev, 1)
+    model, tr = _make_big(dev) if big else _make(dev, 1)
     assert tr.reducers[0].active and tr.reducers[0].direct is not None, "direct RCCL communicator was not set up"
     # "layer": six ncclAllReduce calls per step on the side stream (final layer + loss, hidden layers, first layer), each
     # behind an event of the compute stream; "none": one call on the compute stream after the backward
     assert tr.overlap == (overlap == "layer") and (tr.reducers[0].stream is not None) == (overlap == "layer")
-    losses = _run(tr, dev)
+    losses = _run_big(tr, dev) if big else _run(tr, dev)
     np.save(os.path.join(out_dir, "flat_direct.npy"), tr.flat.detach().cpu().numpy())
     np.save(os.path.join(out_dir, "loss_direct.npy"), np.array(losses))
     # the reduced buffer of a 1-rank communicator is the buffer itself: check the call really ran in place
@@ -141,5 +163,20 @@ def test_direct_rccl_allreduce_single_rank_matches_plain_run(tmp_path, overlap):
     dev = torch.device("cuda", 0)
     model, tr = _make(dev, 1)
     losses = _run(tr, dev)
+    assert np.array_equal(np.load(tmp_path / "loss_direct.npy"), np.array(losses))
+    assert np.array_equal(np.load(tmp_path / "flat_direct.npy"), tr.flat.detach().cpu().numpy())
+
+
+@pytest.mark.parametrize("overlap", ["layer", "none"])
+def test_direct_rccl_with_whole_net_kernels_matches_plain_run(tmp_path, overlap):
+    """The same on the round-4 path (wire_fused.hip): a 256-feature sine net at 9 600 rows per step runs the storing forward,
+    the data-gradient chain and ONE weight-gradient launch for all hidden layers; with WIRE_DP_OVERLAP=layer every layer's
+    slice is still announced (wire_grad_ready_fn) after ITS reduction and reduced on the side stream -- same trajectory as
+    the plain run, bit for bit.  wire_occupancy.py:137-158 is the loop being sharded."""
+    port = 29300 + (os.getpid() % 400) + (31 if overlap == "layer" else 37)
+    mp.spawn(_worker_rccl_direct, args=(1, port, str(tmp_path), overlap, True), nprocs=1, join=True)
+    dev = torch.device("cuda", 0)
+    model, tr = _make_big(dev)
+    losses = _run_big(tr, dev)
     assert np.array_equal(np.load(tmp_path / "loss_direct.npy"), np.array(losses))
     assert np.array_equal(np.load(tmp_path / "flat_direct.npy"), tr.flat.detach().cpu().numpy())
