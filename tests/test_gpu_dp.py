@@ -29,7 +29,7 @@ def _make(dev, micro, seed=0):
     return model, FusedTrainer(model, (H, W), target, lr=5e-3, niters=100, micro_shards=micro)
 
 
-HB, WB = 96, 100         # 9 600 points per step: the whole-net kernels (>= 4096 rows), 75 workgroups
+HB, WB = 256, 256        # 65 536 points per step: the whole-net kernels incl. the batched weight-gradient launch (>= 65 536 rows)
 
 
 def _make_big(dev, seed=0):
@@ -169,7 +169,7 @@ def test_direct_rccl_allreduce_single_rank_matches_plain_run(tmp_path, overlap):
 
 @pytest.mark.parametrize("overlap", ["layer", "none"])
 def test_direct_rccl_with_whole_net_kernels_matches_plain_run(tmp_path, overlap):
-    """The same on the round-4 path (wire_fused.hip): a 256-feature sine net at 9 600 rows per step runs the storing forward,
+    """The same on the round-4 path (wire_fused.hip): a 256-feature sine net at 65 536 rows per step runs the storing forward,
     the data-gradient chain and ONE weight-gradient launch for all hidden layers; with WIRE_DP_OVERLAP=layer every layer's
     slice is still announced (wire_grad_ready_fn) after ITS reduction and reduced on the side stream -- same trajectory as
     the plain run, bit for bit.  wire_occupancy.py:137-158 is the loop being sharded."""
