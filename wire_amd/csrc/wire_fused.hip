@@ -1078,27 +1078,40 @@ __global__ __launch_bounds__(64 * W, 8 / W) void fused_bwd_kernel(const FusedBwd
         gl[e] = valid ? v : 0.f;
         amx = __builtin_fmaxf(amx, __builtin_fabsf(gl[e]));
       }
-      if (sums) {
-        // g_lin_0^T [x | 1] of the wave's 16 rows: every lane of a DPP row ends with the sum, lane r = 0 stores it
-        float sv[20];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-          for (int d = 0; d < 4; ++d) sv[5 * e + d] = gl[e] * xs[d];
-          sv[5 * e + 4] = gl[e];
-        }
-        fx_row16_sum_n<20>(sv);
-        if ((c.lane & 15) == 0) {
-          float* rp = red + ((size_t)c.wave * P + 16 * cb + 4 * c.g) * 5;
-#pragma unroll
-          for (int q = 0; q < 5; ++q)
-            *reinterpret_cast<f32x4*>(rp + 4 * q) = f32x4{sv[4 * q], sv[4 * q + 1], sv[4 * q + 2], sv[4 * q + 3]};
-        }
-      } else {
+      if (!sums) {
         if constexpr (ABL & 2) asm volatile("" :: "v"(gl));
         else *reinterpret_cast<f32x4*>(gp + 16 * cb) = gl;
       }
       acc[cb] = gl;
+    }
+    if (sums) {
+      // g_lin_0^T [x | 1] of the wave's 16 rows through a wave-private LDS transpose, a quarter of the columns at a time: the
+      // lanes write their 4-column pieces of 4 blocks as rows of T (stride 68 floats: 16-byte aligned, consecutive rows 4
+      // banks apart), then lane c reads column c of the 16 rows (consecutive lanes, consecutive words: conflict-free) beside
+      // the rows' [x] (broadcast reads) -- 30 vector instructions per block where sums over the 16 lanes of a DPP row (the
+      // first edition: 20 chains of four row operations side by side) took 100: - 0.04 ms per step
+      // (profiles/r04_bwd_lsum_ab.txt).  One wave, one in-order LDS queue: no barrier between its writes and its reads.
+      float* Tw = red + (size_t)W * P * 5 + (size_t)c.wave * (16 * 68);
+      float* rv = red + (size_t)W * P * 5 + (size_t)W * (16 * 68) + (size_t)c.wave * 64;
+      const int r16 = c.lane & 15;
+      if (c.g == 0) *reinterpret_cast<f32x4*>(rv + 4 * r16) = f32x4{xs[0], xs[1], xs[2], xs[3]};
+#pragma unroll
+      for (int qt = 0; qt < NB / 4; ++qt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Tw + r16 * 68 + 16 * i + 4 * c.g) = acc[4 * qt + i];
+        float sd[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r2 = 0; r2 < 16; ++r2) {
+          const float t = Tw[r2 * 68 + c.lane];
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(rv + 4 * r2);
+#pragma unroll
+          for (int d = 0; d < 4; ++d) sd[d] = __builtin_fmaf(t, xv[d], sd[d]);
+          sd[4] += t;
+        }
+        float* rp = red + ((size_t)c.wave * P + 64 * qt + c.lane) * 5;
+#pragma unroll
+        for (int d = 0; d < 5; ++d) rp[d] = sd[d];
+      }
     }
     if (sums) {
       __syncthreads();
@@ -1300,6 +1313,7 @@ static std::atomic<int> g_fxb_ablate{0};
 template <int KIND, int W, int ABL = 0>
 static hipError_t fxb_launch_w(hipStream_t s, const FusedBwdParams& fp) {
   constexpr int NB = 16, RING = W == 8 ? 3 : 2, LDS = RING * NB * 2048;
+  static_assert((W * 16 * NB * 5 + W * 16 * 68 + W * 64) * 4 <= LDS, "sums: partials + transpose tiles + row vectors in the ring");
   const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_bwd_kernel<KIND, NB, RING, W, ABL>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (attr != hipSuccess) return attr;
