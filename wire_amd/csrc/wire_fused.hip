@@ -24,6 +24,17 @@
 // Layer 0 (D <= 4 inputs) is the same producer with the coordinates as its source; the final linear layer is a dot product
 // per lane + two cross-lane adds.
 //
+// The file's kernels:
+//   fused_fwd_kernel<KIND, NB, RING, ABL, TRAIN, PE>   the forward: TRAIN = 0 forward-only (coordinates in, y out); 1 / 2 the
+//       training forward, storing what the backward reads on the way (2: sine / Gaussian nets behind the chain store r = c lin
+//       of every layer and no out at all); PE: positional-encoding nets, layer 0 as a GEMM layer on features evaluated in
+//       the lanes; its tails: fx_final (y), fx_tail_train (lin_L), fx_tail_loss (the final stage inside: knob "fused_final")
+//   fused_bwd_kernel<KIND, NB, RING, W, ABL>           the data-gradient chain of the real nets g_lin_L -> ... -> g_lin_1 ->
+//       first-layer gradient sums, the same register chaining with the transposed weight images
+//   fx_split_b_kernel                                  the k-permuted, pre-scaled 2 x fp16 weight images of both
+// (ABL != 0: timing probes, instantiated in harness builds only -- EXTRA=-DWIRE_FX_ABLATE, tools/fused_ablate.py,
+//  tools/fused_bwd_ablate.py.)
+//
 // Arithmetic = the 2 x fp16 split of wire_gemmx2h.hip (three partial products per fp32 product, fp32 accumulate, power-of-two
 // operand scales: the weights' from their maximum slots, the activations' from their a-priori bound or the wave's own
 // maximum), hardware transcendentals on pre-scaled arguments for every layer (below: "activations from pre-scaled ...").

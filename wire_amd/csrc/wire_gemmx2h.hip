@@ -542,7 +542,8 @@ hipError_t launch_gemmx2h_nt(hipStream_t s, int epi, const float* A, int lda, co
 // tile without waste:
 //     WM x WN waves, each 64 features of G x 128 features of Z  ->  tile (64 WM) x (128 WN)
 //     (4, 2): 256 x 256, 8 waves  -- padded widths that are multiples of 256 (K = 256: 512; the 256-feature real nets)
-//     (6, 1): 384 x 128, 6 waves  -- hidden_features = 256 through the reference's API: K = 181, P = 384
+//     (8, 1) x 48: 384 x 128, 8 waves of 48 features of G (RB = 3) -- hidden_features = 256 through the reference's API:
+//             K = 181, P = 384 (round 4; round 3's (6, 1): 6 waves x 64 stays behind "x2_tn_p384" = 6)
 //     (7, 1): 448 x 128, 7 waves  -- the occupancy net as written (3 x 300 -> K = 212, P = 448; its last Z tile is half)
 //   (other widths -- config 1's K = 90, P = 192 -- keep the 128 x 128 3 x bf16 kernel of wire_gemmx3.hip)
 //  * the loader splits every fp32 value of a stage once (6 vector ops per 2 values) and stores two fp16 planes per
@@ -554,8 +555,9 @@ hipError_t launch_gemmx2h_nt(hipStream_t s, int epi, const float* A, int lda, co
 //    16 rows:  Z (h | l) x G (l | h) -> h l + l h.  Three MFMAs per 16 x 16 block and 32 rows (six in the 3 x bf16 kernel).
 //    Row slot of row r: (r & 3) | ((r >> 3) & 3) << 2 | ((r >> 2) & 1) << 4 -- every fragment address is the lane's base
 //    plus an immediate (+ 512: rows + 4; + 256: rows + 16; + 1024: next feature block);
-//  * two stage buffers of (64 WM + 128 WN) x 128 bytes (64 KB at (4, 2) and (6, 1)), one workgroup per CU; waves >= 4 (SIMD
-//    partners of waves 0-3) run half a stage apart;
+//  * two stage buffers of (64 WM + 128 WN) x 128 bytes (64 KB at (4, 2), (6, 1) and (8, 1) x 48), one workgroup per CU; waves
+//    >= 4 (SIMD partners of waves 0-3) run half a stage apart ((4, 2) and (8, 1) x 48);
+//  * blockIdx.y = member of a batch of equal-shaped weight gradients (the hidden layers behind wire_fused.hip's chain);
 //  * G and Z carry their own power-of-two scales (maximum slots of their producers); the slabs are unscaled on the way out.
 // ---------------------------------------------------------------------------
 typedef short x2s16x4 __attribute__((ext_vector_type(4)));
